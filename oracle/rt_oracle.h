@@ -1,0 +1,122 @@
+/*
+ * rt_oracle.h -- CPU restatement of the reference trace loop.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is the parity oracle for the MI355X render backend: a plain-C, single-precision, uncontracted
+ * (-ffp-contract=off) restatement of the hot path of avneic/RayTracing
+ *   renderScene -> _renderJob -> (Camera::getRay, _color -> _sceneHit -> sphereHit, materialScatter)
+ * (raytracer.cpp:60-304, sphere.cpp:68-102, material.cu:17-138, camera.h:20-86, utils.cu:65-94,
+ *  vector_cuda.h operator order).  Every function cites the reference lines it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The product
+ * (raytracing_amd/, include/rtx.h, librtx.so) never links, loads or calls it.
+ *
+ * Pinning: the reference ships no golden vectors for this path.  The oracle is pinned against
+ * the reference ITSELF, compiled from /root/reference by oracle/Makefile into oracle/_ref/ (g++, unmodified
+ * raytracer.cpp / sphere.cpp / material.cu / camera.h; only utils.cu -- which cannot compile on Linux -- is
+ * replaced by a host file that draws from the injected stream below).  tests/golden/ holds the vectors that
+ * harness produced (function KATs, primary-hit maps, full-path renders) and tests/test_oracle_*.py checks this
+ * restatement against them bit for bit.  Philox4x32-10 is pinned by the Random123 known-answer vectors.
+ *
+ * The one thing the reference leaves undefined is its random stream (a random_device-seeded, thread-racy
+ * mt19937, utils.cu:26-28).  The oracle and the GPU backend share a counter-based stream instead:
+ *
+ *   Philox4x32-10, key = (seed_lo, seed_hi), counter = (slot, sample, pixel, 0), pixel = y*cols + x,
+ *   sample = global sample index, slot = event*32 + block, uniform float = (u32 >> 8) * 2^-24.
+ *   event 0 (camera):   block 0 = (jitter_u, jitter_v, disk try 0 x, disk try 0 y);
+ *                       disk try t >= 1 -> block (t+1)/2, words (0,1) if t is odd, (2,3) if t is even.
+ *   event e >= 1 (e-th materialScatter call of the path):
+ *                       randomInUnitSphere try t (0..20) -> block t, words (0,1,2) = (x,y,z);
+ *                       glass reflect/refract draw -> block 0, word 0.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } ro_vec3;                                   /* vector_cuda.h:8-76 */
+typedef struct { ro_vec3 origin, direction; } ro_ray;                       /* ray.h:7-20 */
+
+enum { RO_MATERIAL_NONE = 0, RO_MATERIAL_DIFFUSE = 1, RO_MATERIAL_METAL = 2, RO_MATERIAL_GLASS = 3 }; /* material.h:9-14 */
+
+typedef struct { uint32_t type; ro_vec3 albedo; float blur; float ior; } ro_material;            /* material.h:17-38, 24 B */
+typedef struct { ro_vec3 center; float radius; ro_material material; } ro_sphere;               /* sphere.h:24-28, 40 B */
+typedef struct { float distance; ro_vec3 point; ro_vec3 normal; ro_material material; } ro_hit; /* material.h:41-53, 52 B */
+typedef struct { ro_vec3 origin, leftCorner, horizontal, vertical, u, v, w; float lensRadius; } ro_camera; /* camera.h:94-101 */
+
+/* ---- random stream ------------------------------------------------------------------------------------ */
+
+void  ro_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+float ro_u32_to_unit(uint32_t x);
+
+typedef struct {
+    uint32_t key[2];
+    uint32_t pixel, sample;
+    uint32_t event;        /* 0 = camera phase, e = e-th scatter event */
+    uint32_t bare_calls;   /* bare ro_random() calls made in the camera phase (jitter u, jitter v) */
+    const float* inject;   /* when non-NULL: draws come from this list, in call order (function KATs) */
+    uint32_t inject_n, inject_pos;
+    uint64_t draws;        /* number of uniform floats handed out */
+} ro_rng;
+
+void    ro_rng_begin_sample(ro_rng* g, uint64_t seed, uint32_t pixel, uint32_t sample);
+void    ro_rng_inject(ro_rng* g, const float* draws, uint32_t n);
+float   ro_random(ro_rng* g);                   /* utils.cu:65-72 */
+ro_vec3 ro_random_in_unit_sphere(ro_rng* g);    /* utils.cu:74-83 */
+ro_vec3 ro_random_on_unit_disk(ro_rng* g);      /* utils.cu:85-94 */
+
+/* ---- the path ------------------------------------------------------------------------------------------ */
+
+int     ro_sphere_hit(const ro_sphere* s, const ro_ray* r, float tmin, float tmax, ro_hit* hit);                       /* sphere.cpp:68-102 */
+int     ro_scene_hit(const ro_sphere* scene, uint32_t n, const ro_ray* r, float tmin, float tmax, ro_hit* hit, uint32_t* index); /* raytracer.cpp:285-304 */
+ro_vec3 ro_reflect(ro_vec3 v, ro_vec3 n);                                                                              /* material.cu:112-115 */
+int     ro_refract(ro_vec3 v, ro_vec3 n, float ni_over_nt, ro_vec3* refracted);                                        /* material.cu:118-129 */
+float   ro_schlick(float cosine, float ior);                                                                           /* material.cu:132-138 */
+int     ro_material_scatter(const ro_material* m, const ro_ray* r, const ro_hit* hit, ro_vec3* attenuation, ro_ray* scattered, ro_rng* g); /* material.cu:17-105 */
+ro_vec3 ro_background(const ro_ray* r);                                                                                /* raytracer.cpp:276-282 */
+void    ro_camera_init(ro_camera* cam, float vfov, float aspect, float aperture, float focusDistance,
+                       ro_vec3 pos, ro_vec3 up, ro_vec3 lookat);                                                       /* camera.h:20-41 */
+ro_ray  ro_camera_get_ray(const ro_camera* cam, float s, float t, ro_rng* g);                                          /* camera.h:75-86 */
+
+typedef struct {
+    uint64_t samples, rays, sphere_tests;
+    uint64_t term_miss, term_absorb, term_depth;
+} ro_stats;
+
+/* raytracer.cpp:243-273 (iterative, the default) and :213-240 (recursive, -r).  *first_hit receives the sphere
+ * index of the first _sceneHit call (0xFFFFFFFF on a miss) when non-NULL. */
+ro_vec3 ro_color(const ro_ray* r, const ro_sphere* scene, uint32_t n, uint32_t max_depth, ro_rng* g, uint32_t* first_hit, ro_stats* st);
+ro_vec3 ro_color_recursive(const ro_ray* r, const ro_sphere* scene, uint32_t n, uint32_t depth, uint32_t max_depth, ro_rng* g, uint32_t* first_hit, ro_stats* st);
+
+/* _renderJob's per-pixel sample loop (raytracer.cpp:175-186) for samples [spp_begin, spp_begin+spp_count) of
+ * pixel (x,y).  Samples are summed in index order inside chunks of chunk_spp (0 = one chunk = the reference's
+ * order) and the chunk sums are then summed in chunk order -- the order the GPU backend uses.  primary_hit
+ * (may be NULL) gets spp_count entries. */
+ro_vec3 ro_pixel_sum(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+                     uint32_t x, uint32_t y, uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp,
+                     uint32_t max_depth, uint64_t seed, int recursive, uint32_t* primary_hit, uint32_t primary_stride, ro_stats* st);
+
+/* Whole frame, nthreads worker threads pulling tile x tile pixel blocks from a shared counter (the role of
+ * thread_pool.cpp + raytracer.cpp:93-127).  accum_rgb: rows*cols*3 floats, the un-normalised colour sums.
+ * primary_hit (may be NULL): spp_count*rows*cols entries, [(s-spp_begin)*rows*cols + y*cols + x]. */
+int ro_render(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+              uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp, uint32_t max_depth, uint64_t seed,
+              int recursive, uint32_t nthreads, uint32_t tile, float* accum_rgb, uint32_t* primary_hit, ro_stats* st);
+
+/* raytracer.cpp:187-197: /= spp, sqrt, (uint8_t)(255.99 * c) in double, pack R<<24|G<<16|B<<8.
+ * debug_tile != 0 reproduces -d (raytracer.cpp:168-171): pixels on tile borders become 0xFF000000. */
+void ro_resolve(const float* accum_rgb, uint32_t rows, uint32_t cols, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer);
+
+/* RayTracing.cpp:182-213 driven by the Philox stream (counter = (draw, 0, 0, 0x5CE9E), key = seed).
+ * grid_half = 11 and p_diffuse = 0.8f, p_metal = 0.95f give the book-1 layout; returns the sphere count
+ * (<= ro_random_scene_capacity(grid_half)). */
+uint32_t ro_random_scene_capacity(int grid_half);
+uint32_t ro_random_scene(uint64_t seed, int grid_half, float p_diffuse, float p_metal, ro_sphere* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,190 @@
+"""The CPU oracle (oracle/rt_oracle.c) against vectors produced by the compiled reference (oracle/_ref, see
+oracle/gen_fixtures.py).  Every comparison is on raw float bits."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, bits
+
+
+def _v(o, a):
+    return o.vec3(a)
+
+
+def test_reference_struct_sizes():
+    # sphere.h:24-28, material.h:17-53 -- the oracle's PODs have the reference's layout
+    import pyoracle as o
+    with open(os.path.join(GOLDEN, "ref_sizes.json")) as f:
+        s = json.load(f)
+    assert C.sizeof(o.Sphere) == s["sphere_t"] == 40
+    assert C.sizeof(o.Material) == s["material_t"] == 24
+    assert C.sizeof(o.Hit) == s["hit_info"] == 52
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32-10
+    assert oracle.philox((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox((0xffffffff,) * 4, (0xffffffff,) * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    L = oracle.lib()
+    assert L.ro_u32_to_unit(0) == 0.0
+    assert L.ro_u32_to_unit(0xFFFFFFFF) == np.float32(1.0) - np.float32(2.0 ** -24)
+    assert L.ro_u32_to_unit(0x80000000) == 0.5
+
+
+def test_sphere_hit_kat(oracle, golden_kat):
+    L = oracle.lib()
+    rows = golden_kat["kat_sphere_hit"]
+    nhit = 0
+    for r in rows:
+        s = oracle.Sphere(_v(oracle, r[0:3]), float(r[3]), oracle.Material(1, _v(oracle, (0, 0, 0)), 0.0, 1.0))
+        ray = oracle.Ray(_v(oracle, r[4:7]), _v(oracle, r[7:10]))
+        h = oracle.Hit()
+        ret = L.ro_sphere_hit(C.byref(s), C.byref(ray), float(r[10]), float(r[11]), C.byref(h))
+        assert ret == int(r[12])
+        if ret:
+            nhit += 1
+            got = np.array([h.distance, h.point.x, h.point.y, h.point.z, h.normal.x, h.normal.y, h.normal.z], dtype=np.float32)
+            assert (bits(got) == bits(r[13:20])).all()
+    assert 0.3 * len(rows) < nhit < 0.95 * len(rows)
+
+
+def test_optics_kat(oracle, golden_kat):
+    L = oracle.lib()
+    for r in golden_kat["kat_optics"]:
+        v, n = _v(oracle, r[0:3]), _v(oracle, r[3:6])
+        refl = oracle.v3np(L.ro_reflect(v, n))
+        assert (bits(refl) == bits(r[9:12])).all()
+        out = oracle.Vec3()
+        ok = L.ro_refract(v, n, float(r[6]), C.byref(out))
+        assert ok == int(r[12])
+        if ok:
+            assert (bits(oracle.v3np(out)) == bits(r[13:16])).all()
+        sch = np.float32(L.ro_schlick(float(r[7]), float(r[8])))
+        assert bits(sch) == bits(r[16])
+
+
+def test_background_kat(oracle, golden_kat):
+    L = oracle.lib()
+    for r in golden_kat["kat_background"]:
+        ray = oracle.Ray(_v(oracle, (0, 0, 0)), _v(oracle, r[0:3]))
+        assert (bits(oracle.v3np(L.ro_background(C.byref(ray)))) == bits(r[3:6])).all()
+
+
+def test_samplers_kat(oracle, golden_kat):
+    L = oracle.lib()
+    exhausted = 0
+    for r in golden_kat["kat_samplers"]:
+        d = oracle.kat_draws(int(r[0]), 1, 64, int(r[1]))
+        g = oracle.Rng()
+        L.ro_rng_inject(C.byref(g), d.ctypes.data_as(C.POINTER(C.c_float)), 64)
+        p = oracle.v3np(L.ro_random_in_unit_sphere(C.byref(g)))
+        assert (bits(p) == bits(r[2:5])).all() and g.inject_pos == int(r[5])
+        exhausted += int(r[5]) == 63
+        L.ro_rng_inject(C.byref(g), d.ctypes.data_as(C.POINTER(C.c_float)), 64)
+        p = oracle.v3np(L.ro_random_on_unit_disk(C.byref(g)))
+        assert (bits(p) == bits(r[6:9])).all() and g.inject_pos == int(r[9])
+    assert exhausted >= 10   # the 21-try exhaustion case of utils.cu:77-80 is covered
+
+
+def test_camera_kat(oracle, golden_kat):
+    for r in golden_kat["kat_camera"]:
+        cam = oracle.camera(float(r[0]), float(r[1]), float(r[2]), float(r[3]), r[4:7], r[7:10], r[10:13])
+        assert (bits(oracle.camera_to_array(cam)) == bits(r[13:35])).all()
+
+
+def test_get_ray_kat(oracle, golden_kat):
+    L = oracle.lib()
+    for r in golden_kat["kat_get_ray"]:
+        cam = oracle.camera_from_array(r[0:22])
+        d = oracle.kat_draws(int(r[24]), 2, 42, int(r[25]))
+        g = oracle.Rng()
+        L.ro_rng_inject(C.byref(g), d.ctypes.data_as(C.POINTER(C.c_float)), 42)
+        ray = L.ro_camera_get_ray(C.byref(cam), float(r[22]), float(r[23]), C.byref(g))
+        got = np.concatenate([oracle.v3np(ray.origin), oracle.v3np(ray.direction)])
+        assert (bits(got) == bits(r[26:32])).all() and g.inject_pos == int(r[32])
+
+
+def test_scatter_kat(oracle, golden_kat):
+    L = oracle.lib()
+    seen = {1: 0, 2: 0, 3: 0}
+    absorbed = 0
+    for r in golden_kat["kat_scatter"]:
+        m = oracle.Material(int(r[0]), _v(oracle, r[1:4]), float(r[4]), float(r[5]))
+        ray = oracle.Ray(_v(oracle, r[6:9]), _v(oracle, r[9:12]))
+        h = oracle.Hit(float(r[12]), _v(oracle, r[13:16]), _v(oracle, r[16:19]), m)
+        d = oracle.kat_draws(int(r[19]), 3, 64, int(r[20]))
+        g = oracle.Rng()
+        L.ro_rng_inject(C.byref(g), d.ctypes.data_as(C.POINTER(C.c_float)), 64)
+        att, sc = oracle.Vec3(), oracle.Ray()
+        ret = L.ro_material_scatter(C.byref(m), C.byref(ray), C.byref(h), C.byref(att), C.byref(sc), C.byref(g))
+        assert ret == int(r[21])
+        got = np.concatenate([oracle.v3np(att), oracle.v3np(sc.origin), oracle.v3np(sc.direction)])
+        assert (bits(got) == bits(r[22:31])).all(), (int(r[0]), got, r[22:31])
+        assert g.inject_pos == int(r[31])
+        seen[int(r[0])] += 1
+        absorbed += ret == 0
+    assert min(seen.values()) > 100 and absorbed > 5
+
+
+def _render_frame(oracle, scenes, f, chunk=0):
+    cam = oracle.book_camera(f["cols"], f["rows"])
+    return oracle.render(scenes[f["scene"]], cam, f["rows"], f["cols"], f["spp_begin"], f["spp_count"], f["max_depth"],
+                         f["seed"], chunk_spp=chunk, recursive=bool(f["recursive"]), want_primary=True)
+
+
+def test_frames_bit_exact(oracle, golden_scenes, golden_frames):
+    """Whole paths: primary-hit index maps, colour sums and the reference's own _renderJob output."""
+    for name, f in golden_frames.items():
+        accum, primary, st = _render_frame(oracle, golden_scenes, f)
+        npix = f["rows"] * f["cols"]
+        if "primary" in f:
+            assert (primary == f["primary"]).all(), name
+            assert int((primary == 0xFFFFFFFF).sum()) == f["primary_miss"]
+        if "accum" in f:
+            assert (bits(accum) == bits(f["accum"])).all(), name
+        if "fb" in f:
+            fb = oracle.resolve(accum, f["rows"], f["cols"], f["spp_count"])
+            assert (fb == f["fb"]).all(), name
+        assert st["samples"] == npix * f["spp_count"]
+        assert st["sphere_tests"] == st["rays"] * f["n"]
+        assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
+
+
+def test_chunked_sum_matches_within_rounding(oracle, golden_scenes, golden_frames):
+    f = golden_frames["book1_75x50_spp16"]
+    a0, _, _ = _render_frame(oracle, golden_scenes, f, chunk=0)
+    a4, _, _ = _render_frame(oracle, golden_scenes, f, chunk=4)
+    assert np.allclose(a0, a4, rtol=1e-5, atol=1e-6)
+    assert (bits(a0) != bits(a4)).any()   # a different association order, visible in the last bits
+
+
+def test_scene_generator_matches_golden(oracle, golden_scenes):
+    with open(os.path.join(GOLDEN, "scenes.json")) as fjs:
+        meta = json.load(fjs)
+    for key, kw in meta.items():
+        t = oracle.random_scene(kw["seed"], kw["grid_half"], kw["p_diffuse"], kw["p_metal"])
+        assert len(t) == kw["n"] and (bits(t) == bits(golden_scenes[key])).all()
+    book = golden_scenes["book1"]
+    assert 484 <= len(book) <= 488                      # 484-488 spheres
+    frac = [(book[1:-3, 4] == k).mean() for k in (1, 2, 3)]
+    assert 0.7 < frac[0] < 0.9 and frac[1] < 0.1 and 0.08 < frac[2] < 0.25   # 80 / 5 / 15 % (RayTracing.cpp:194-200)
+    glass = golden_scenes["glass"]
+    assert (glass[1:-3, 4] == 3).mean() >= 0.8
+
+
+def test_statistical_agreement_with_unmodified_reference(oracle, golden_scenes):
+    """The unmodified renderScene (its own mt19937 draws) and the oracle (Philox) are two independent Monte Carlo
+    estimates of one image: at 1024 spp each they must agree to well over 40 dB."""
+    with open(os.path.join(GOLDEN, "refrender.json")) as fjs:
+        m = json.load(fjs)["book1_120x80_spp1024"]
+    ref = np.load(os.path.join(GOLDEN, "refrender_book1_120x80_spp1024.npz"))["fb"]
+    spp = 256  # the oracle side at 256 spp keeps the CPU suite fast; MSE ~ s^2 (1/1024 + 1/256)
+    cam = oracle.book_camera(m["cols"], m["rows"])
+    accum, _, _ = oracle.render(golden_scenes["book1"], cam, m["rows"], m["cols"], 0, spp, m["max_depth"], 11)
+    fb = oracle.resolve(accum, m["rows"], m["cols"], spp)
+    psnr, rmse = oracle.psnr_rgb8(fb, ref)
+    assert psnr > 36.0, (psnr, rmse)
