@@ -1,0 +1,151 @@
+/*
+ * rtx.h -- C ABI of the MI355X (gfx950) render backend for the per-pixel trace loop of avneic/RayTracing.
+ *
+ * The library behind this header (raytracing_amd/csrc -> librtx.so) replaces, for the path
+ *   renderScene -> _renderJob -> (Camera::getRay, _color -> _sceneHit -> sphereHit, materialScatter)
+ * what the reference implements three times behind one signature (raytracer.h:17-19: renderScene,
+ * renderSceneCUDA, renderSceneISPC).  It is the fourth backend: `renderSceneHIP` (raytracing_amd/host/
+ * render_scene_hip.h) has that same signature and is a thin C++ wrapper over the calls below, the way
+ * renderSceneISPC is a wrapper over the extern "C" pair cameraInitISPC / renderISPC (raytracer_ispc.h:93-95)
+ * that take one POD context (raytracer_ispc.h:44-64).
+ *
+ * Conventions: every call returns 0 on success and a negative rtx_status on failure; rtx_last_error() returns
+ * the message of the last failure on the calling thread.  All calls block until their work is complete.  A
+ * context belongs to one device and is not thread-safe.  There is NO CPU fallback: without a usable gfx950
+ * device rtx_create fails and nothing else can be called.
+ *
+ * Pointers named *_host are host memory, *_dev are device memory of the context's GPU.  Plain pointers and
+ * sizes only -- no C++ or torch types cross this boundary.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RTX_OK            = 0,
+    RTX_ERR_ARG       = -1,  /* bad argument (null pointer, zero size, unknown material type, ...) */
+    RTX_ERR_DEVICE    = -2,  /* no gfx950 device / HIP runtime error */
+    RTX_ERR_STATE     = -3,  /* call order (render before scene/camera upload, ...) */
+    RTX_ERR_NOMEM     = -4
+} rtx_status;
+
+/* material.h:9-14 (material_type_t) */
+enum { RTX_MATERIAL_NONE = 0, RTX_MATERIAL_DIFFUSE = 1, RTX_MATERIAL_METAL = 2, RTX_MATERIAL_GLASS = 3 };
+
+/* The derived camera of camera.h:94-101 (what Camera's constructor computes, camera.h:20-41). */
+typedef struct rtx_camera {
+    float origin[3];
+    float left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float w[3];
+    float lens_radius;
+} rtx_camera;
+
+/* rtx_render flags */
+enum {
+    RTX_FLAG_ACCUMULATE = 1u << 0,  /* add this call's colour sums to the accumulation buffer instead of replacing it */
+    RTX_FLAG_RECURSIVE  = 1u << 1   /* the -r semantics of raytracer.cpp:213-240 (absorbed / over-depth paths are black) */
+};
+
+/* Counters gathered inside the kernel with wave ballots (rays = _sceneHit calls, raytracer.cpp:251). */
+typedef struct rtx_stats {
+    uint64_t samples;
+    uint64_t rays;
+    uint64_t sphere_tests;      /* rays * n: every ray is tested against the whole list, as in raytracer.cpp:291-300 */
+    uint64_t term_miss;         /* paths ended on the background (raytracer.cpp:266-269) */
+    uint64_t term_absorb;       /* paths ended by materialScatter returning false (raytracer.cpp:262-264) */
+    uint64_t term_depth;        /* paths that used up max_depth bounces (raytracer.cpp:250) */
+    uint64_t candidates;        /* (ray, sphere) pairs that went through the exact sphereHit arithmetic */
+    double   kernel_ms;         /* trace + reduce kernels, HIP events on the context's stream */
+} rtx_stats;
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+
+/* Replaces the per-call pool/scene set-up of raytracer.cpp:62-90 (and raytracer.cu:57-109): binds a context to
+ * HIP device `device_id`, creates its stream.  Fails with RTX_ERR_DEVICE when the device is absent or not gfx950. */
+int rtx_create(int device_id, rtx_ctx** out_ctx);
+int rtx_destroy(rtx_ctx* ctx);
+const char* rtx_last_error(void);
+
+/* ---- inputs -------------------------------------------------------------------------------------------- */
+
+/* Replaces the AoS flatten of raytracer.cpp:76-90 / raytracer.cu:77-94: n spheres as SoA host arrays (copied).
+ * mat_type[i] in {DIFFUSE, METAL, GLASS}; albedo, blur, ior as material.h:17-38.  n may be 0. */
+int rtx_upload_scene(rtx_ctx* ctx, uint32_t n,
+                     const float* cx_host, const float* cy_host, const float* cz_host, const float* radius_host,
+                     const uint32_t* mat_type_host,
+                     const float* albedo_r_host, const float* albedo_g_host, const float* albedo_b_host,
+                     const float* blur_host, const float* ior_host);
+
+/* Replaces raytracer.cu:68-73 (_createCamera) / raytracerispc.cpp:91-103 (cameraInitISPC). */
+int rtx_set_camera(rtx_ctx* ctx, const rtx_camera* cam);
+
+/* ---- the hot path ---------------------------------------------------------------------------------------- */
+
+/* Replaces the tile fan-out and _renderJob's sample loop (raytracer.cpp:93-133, :145-186; raytracer.cu:112-114):
+ * traces samples [spp_begin, spp_begin + spp_count) of every pixel of a cols x rows image and leaves the per-pixel
+ * colour SUMS (not yet divided by spp) in the context's float accumulation buffer, rows*cols*3 floats, row-major,
+ * row 0 on top, RGB interleaved.
+ *   seed       : key of the Philox4x32-10 sample stream ("random stream")
+ *   chunk_spp  : samples summed per work item before the ordered chunk reduction; 0 = choose automatically
+ *   primary_hit_host : NULL, or spp_count*rows*cols uint32 that receive the sphere index of each sample's first
+ *                hit, [(s - spp_begin)*rows*cols + y*cols + x], 0xFFFFFFFF on a miss
+ *   stats      : NULL or counters of this call */
+int rtx_render(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+               uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint32_t* primary_hit_host, rtx_stats* stats);
+
+/* Same, but only enqueues the work on the context's stream and returns; rtx_sync() waits.  bench.py brackets
+ * K of these with one rtx_sync.  Statistics and primary-hit maps are not available in this form. */
+int rtx_render_async(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                     uint64_t seed, uint32_t flags, uint32_t chunk_spp);
+int rtx_sync(rtx_ctx* ctx);
+/* Milliseconds between the first and the last kernel enqueued since the previous rtx_sync (HIP events). */
+int rtx_last_kernel_ms(rtx_ctx* ctx, double* ms);
+
+/* ---- outputs --------------------------------------------------------------------------------------------- */
+
+/* The accumulation buffer in device memory (valid until the next rtx_render with another image size or
+ * rtx_destroy).  The multi-GPU host sums these across ranks in place (RCCL all-reduce) before resolving. */
+int rtx_accum_device(rtx_ctx* ctx, float** accum_dev, size_t* n_floats);
+int rtx_read_accum(rtx_ctx* ctx, float* rgb_host, size_t n_floats);
+int rtx_write_accum(rtx_ctx* ctx, uint32_t cols, uint32_t rows, const float* rgb_host, size_t n_floats);
+
+/* Replaces raytracer.cpp:187-197: colour sum * (1/spp_total), sqrt (gamma 2), (uint8_t)(255.99 * c) in double,
+ * pack R<<24 | G<<16 | B<<8 into the caller's framebuffer (rows*cols uint32, the layout RayTracing.cpp:156-165
+ * unpacks).  debug_tile != 0 paints tile borders 0xFF000000 as -d does (raytracer.cpp:168-171). */
+int rtx_resolve_rgbx8(rtx_ctx* ctx, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host);
+
+/* ---- host-side helpers (no GPU needed) ---------------------------------------------------------------------- */
+
+/* camera.h:20-41: derives the camera from the constructor's arguments, in the constructor's operation order. */
+int rtx_camera_init(rtx_camera* cam, float vfov, float aspect, float aperture, float focus_distance,
+                    const float pos[3], const float up[3], const float lookat[3]);
+
+/* RayTracing.cpp:182-213 (_randomScene), driven by a seeded Philox stream instead of the unseeded mt19937.
+ * grid_half = 11, p_diffuse = 0.8, p_metal = 0.95 is the book-1 final scene.  Arrays must hold
+ * rtx_scene_capacity(grid_half) entries; *n receives the number of spheres written. */
+uint32_t rtx_scene_capacity(int grid_half);
+int rtx_random_scene(uint64_t seed, int grid_half, float p_diffuse, float p_metal, uint32_t* n,
+                     float* cx, float* cy, float* cz, float* radius, uint32_t* mat_type,
+                     float* albedo_r, float* albedo_g, float* albedo_b, float* blur, float* ior);
+
+/* RayTracing.cpp:152-165: "P3\n<cols> <rows>\n255\n" then "r g b\n" per pixel. */
+int rtx_write_ppm(const char* path, uint32_t cols, uint32_t rows, const uint32_t* framebuffer_host);
+
+const char* rtx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,13 @@
+"""raytracing_amd -- MI355X (gfx950) render backend for the per-pixel trace loop of avneic/RayTracing.
+
+The product is the C-ABI library ``librtx.so`` (``include/rtx.h``; sources in ``raytracing_amd/csrc``).  This package
+is its Python host side: a ctypes binding plus a mirror of the reference's operator interface for the path
+(``renderScene`` family, raytracer.h:17-19; ``Scene``/``Sphere``/``material_t``/``Camera``, scene.h, sphere.h,
+material.h, camera.h).  There is no CPU fallback: without the built library, or without a gfx950 device, rendering
+raises.
+"""
+from .api import (Camera, Context, Material, RtxError, Scene, Sphere, Stats, book_camera, lib, random_scene,
+                  render_scene_hip, write_ppm, MATERIAL_DIFFUSE, MATERIAL_GLASS, MATERIAL_METAL, FLAG_ACCUMULATE)
+
+__all__ = ["Camera", "Context", "Material", "RtxError", "Scene", "Sphere", "Stats", "book_camera", "lib", "random_scene",
+           "render_scene_hip", "write_ppm", "MATERIAL_DIFFUSE", "MATERIAL_GLASS", "MATERIAL_METAL", "FLAG_ACCUMULATE"]

@@ -1,0 +1,255 @@
+"""ctypes binding of librtx.so (include/rtx.h) and the host-side mirror of the reference's interface."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtx.so")
+
+MATERIAL_NONE, MATERIAL_DIFFUSE, MATERIAL_METAL, MATERIAL_GLASS = 0, 1, 2, 3   # material.h:9-14
+FLAG_ACCUMULATE, FLAG_RECURSIVE = 1, 2
+
+# every symbol include/rtx.h declares
+EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_camera", "rtx_render",
+           "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
+           "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_version"]
+
+
+class RtxError(RuntimeError):
+    pass
+
+
+class CCamera(C.Structure):
+    """rtx_camera: the derived camera of camera.h:94-101."""
+    _fields_ = [("origin", C.c_float * 3), ("left_corner", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("lens_radius", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64), ("term_miss", C.c_uint64),
+                ("term_absorb", C.c_uint64), ("term_depth", C.c_uint64), ("candidates", C.c_uint64), ("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Loads librtx.so.  Raises if it has not been built -- there is no other implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtxError("%s is missing: build it with `make -C raytracing_amd/csrc` (or __graft_entry__.build()); "
+                       "raytracing_amd has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    P, u32, u64, f32 = C.POINTER, C.c_uint32, C.c_uint64, C.c_float
+    fp, up = P(f32), P(u32)
+    L.rtx_last_error.restype = C.c_char_p
+    L.rtx_version.restype = C.c_char_p
+    L.rtx_create.argtypes = [C.c_int, P(C.c_void_p)]
+    L.rtx_destroy.argtypes = [C.c_void_p]
+    L.rtx_upload_scene.argtypes = [C.c_void_p, u32, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
+    L.rtx_set_camera.argtypes = [C.c_void_p, P(CCamera)]
+    L.rtx_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, up, P(Stats)]
+    L.rtx_render_async.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32]
+    L.rtx_sync.argtypes = [C.c_void_p]
+    L.rtx_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double)]
+    L.rtx_accum_device.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t)]
+    L.rtx_read_accum.argtypes = [C.c_void_p, fp, C.c_size_t]
+    L.rtx_write_accum.argtypes = [C.c_void_p, u32, u32, fp, C.c_size_t]
+    L.rtx_resolve_rgbx8.argtypes = [C.c_void_p, u32, u32, up]
+    L.rtx_camera_init.argtypes = [P(CCamera), f32, f32, f32, f32, fp, fp, fp]
+    L.rtx_scene_capacity.restype = u32
+    L.rtx_scene_capacity.argtypes = [C.c_int]
+    L.rtx_random_scene.argtypes = [u64, C.c_int, f32, f32, up, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
+    L.rtx_write_ppm.argtypes = [C.c_char_p, u32, u32, up]
+    for name in EXPORTS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtxError("rtx error %d: %s" % (rc, lib().rtx_last_error().decode()))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+# ---- the reference's scene-construction interface, mirrored ----------------------------------------------------
+
+class Material:
+    """material_t, material.h:17-38 (same defaults)."""
+
+    def __init__(self, type=MATERIAL_NONE, albedo=(1.0, 0.0, 1.0), blur=1.0, refractionIndex=1.0):
+        self.type, self.albedo, self.blur, self.refractionIndex = int(type), tuple(albedo), float(blur), float(refractionIndex)
+
+
+class Sphere:
+    """Sphere, sphere.h:10-21."""
+
+    def __init__(self, pos=(0.0, 0.0, 0.0), radius=1.0, material=None):
+        self.center, self.radius, self.material = tuple(pos), float(radius), material
+
+
+class Scene:
+    """Scene, scene.h:22-47: a list of objects.  `table()` is the flatten step of raytracer.cpp:76-90, to SoA."""
+
+    def __init__(self, objects=None):
+        self.objects = list(objects or [])
+
+    @classmethod
+    def from_table(cls, table):
+        t = np.asarray(table, dtype=np.float32).reshape(-1, 10)
+        return cls([Sphere(r[0:3], r[3], Material(int(r[4]), r[5:8], r[8], r[9])) for r in t])
+
+    def table(self):
+        t = np.zeros((len(self.objects), 10), dtype=np.float32)
+        for i, s in enumerate(self.objects):
+            if not isinstance(s, Sphere) or s.material is None:
+                raise RtxError("object %d is not a Sphere with a material (raytracer.cpp:82 dynamic_casts to Sphere)" % i)
+            m = s.material
+            t[i] = [s.center[0], s.center[1], s.center[2], s.radius, m.type, m.albedo[0], m.albedo[1], m.albedo[2], m.blur, m.refractionIndex]
+        return t
+
+
+class Camera:
+    """Camera, camera.h:15-102: same constructor arguments and defaults; the derivation runs in librtx's host code."""
+
+    def __init__(self, vfov=50.0, aspect=2.0, aperture=1.0, focusDistance=3.402823466e+38, pos=(0, 0, 0), up=(0, 1, 0), lookat=(0, 0, -1)):
+        self.c = CCamera()
+        a = [np.asarray(v, dtype=np.float32) for v in (pos, up, lookat)]
+        _check(lib().rtx_camera_init(C.byref(self.c), np.float32(vfov), np.float32(aspect), np.float32(aperture), np.float32(focusDistance), _fp(a[0]), _fp(a[1]), _fp(a[2])))
+
+    def as_array(self):
+        c = self.c
+        return np.array(list(c.origin) + list(c.left_corner) + list(c.horizontal) + list(c.vertical) + list(c.u) + list(c.v) + list(c.w) + [c.lens_radius], dtype=np.float32)
+
+
+def book_camera(cols, rows):
+    """The camera main() builds, RayTracing.cpp:107-117, with aspect = cols / rows."""
+    return Camera(20.0, np.float32(cols) / np.float32(rows), 0.1, 10.0, (13, 2, 3), (0, 1, 0), (0, 0, 0))
+
+
+def random_scene(seed=1, grid_half=11, p_diffuse=0.8, p_metal=0.95):
+    """_randomScene(), RayTracing.cpp:182-213, seeded.  Returns the [n,10] table (cx cy cz r type ar ag ab blur ior)."""
+    L = lib()
+    cap = L.rtx_scene_capacity(grid_half)
+    f = [np.zeros(cap, dtype=np.float32) for _ in range(9)]
+    t = np.zeros(cap, dtype=np.uint32)
+    n = C.c_uint32(0)
+    _check(L.rtx_random_scene(seed, grid_half, p_diffuse, p_metal, C.byref(n), _fp(f[0]), _fp(f[1]), _fp(f[2]), _fp(f[3]), _up(t),
+                              _fp(f[4]), _fp(f[5]), _fp(f[6]), _fp(f[7]), _fp(f[8])))
+    n = n.value
+    return np.stack([f[0][:n], f[1][:n], f[2][:n], f[3][:n], t[:n].astype(np.float32), f[4][:n], f[5][:n], f[6][:n], f[7][:n], f[8][:n]], axis=1)
+
+
+def write_ppm(path, cols, rows, framebuffer):
+    fb = np.ascontiguousarray(framebuffer, dtype=np.uint32)
+    _check(lib().rtx_write_ppm(str(path).encode(), cols, rows, _up(fb)))
+
+
+# ---- the backend ---------------------------------------------------------------------------------------------------
+
+class Context:
+    """One rtx_ctx: one GPU, one stream."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().rtx_create(device, C.byref(self._h)))
+        self.cols = self.rows = 0
+
+    def close(self):
+        if self._h:
+            lib().rtx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, table):
+        t = np.ascontiguousarray(np.asarray(table, dtype=np.float32).reshape(-1, 10))
+        cols = [np.ascontiguousarray(t[:, i]) for i in range(10)]
+        mt = np.ascontiguousarray(t[:, 4].astype(np.uint32))
+        _check(lib().rtx_upload_scene(self._h, len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), _up(mt),
+                                      _fp(cols[5]), _fp(cols[6]), _fp(cols[7]), _fp(cols[8]), _fp(cols[9])))
+        self.n = len(t)
+
+    def set_camera(self, cam):
+        c = cam.c if isinstance(cam, Camera) else cam
+        _check(lib().rtx_set_camera(self._h, C.byref(c)))
+
+    def render(self, cols, rows, spp_begin, spp_count, max_depth, seed, flags=0, chunk_spp=0, want_primary=False, want_stats=True):
+        primary = np.zeros(spp_count * rows * cols, dtype=np.uint32) if want_primary else None
+        st = Stats()
+        _check(lib().rtx_render(self._h, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp,
+                                _up(primary) if want_primary else None, C.byref(st) if want_stats else None))
+        self.cols, self.rows = cols, rows
+        return primary, (st.as_dict() if want_stats else None)
+
+    def render_async(self, cols, rows, spp_begin, spp_count, max_depth, seed, flags=0, chunk_spp=0):
+        _check(lib().rtx_render_async(self._h, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp))
+        self.cols, self.rows = cols, rows
+
+    def sync(self):
+        _check(lib().rtx_sync(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_double(0)
+        _check(lib().rtx_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def accum_device(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().rtx_accum_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_accum(self):
+        a = np.zeros(self.cols * self.rows * 3, dtype=np.float32)
+        _check(lib().rtx_read_accum(self._h, _fp(a), a.size))
+        return a
+
+    def write_accum(self, cols, rows, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        _check(lib().rtx_write_accum(self._h, cols, rows, _fp(a), a.size))
+        self.cols, self.rows = cols, rows
+
+    def resolve(self, spp_total, debug_tile=0):
+        fb = np.zeros(self.cols * self.rows, dtype=np.uint32)
+        _check(lib().rtx_resolve_rgbx8(self._h, spp_total, debug_tile, _up(fb)))
+        return fb
+
+
+def render_scene_hip(scene, camera, rows, cols, frameBuffer, num_aa_samples=4, max_ray_depth=50, numThreads=1, blockSize=64,
+                     debug=False, recursive=True, seed=1, device=0):
+    """renderSceneHIP: the fourth backend behind the signature of raytracer.h:17-19.
+
+    scene/camera are borrowed, frameBuffer (rows*cols uint32, 0xRRGGBB00) is filled, 0 is returned on success --
+    raytracer.cpp:60-143's contract.  numThreads is advisory (as for renderSceneCUDA); blockSize only positions the
+    -d borders.  `recursive` selects the -r semantics; NOTE that main() passes recursive=false unless -r is given
+    (RayTracing.cpp:90-93), whatever the header's default says.
+    """
+    ctx = Context(device)
+    try:
+        ctx.upload_scene(scene.table() if isinstance(scene, Scene) else scene)
+        ctx.set_camera(camera)
+        ctx.render(cols, rows, 0, num_aa_samples, max_ray_depth, seed, FLAG_RECURSIVE if recursive else 0, want_stats=False)
+        fb = ctx.resolve(num_aa_samples, blockSize if debug else 0)
+        np.asarray(frameBuffer).reshape(-1)[:] = fb
+        return 0
+    finally:
+        ctx.close()

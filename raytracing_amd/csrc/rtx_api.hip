@@ -1,0 +1,340 @@
+// rtx_api.hip -- the C ABI of include/rtx.h: context, uploads, launches, read-back.  Host code only; the kernels
+// live in trace_kernel.hip.  No CPU fallback exists: every entry point that renders needs a gfx950 device.
+#include "rtx_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rtx;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct rtx_ctx {
+    int         device = -1;
+    int         num_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev_first = nullptr, ev_last = nullptr;
+    bool        ev_open = false;      // ev_first recorded since the last sync
+    // scene
+    uint32_t n = 0, n_pad = 0;
+    float4*  hot = nullptr;
+    float4*  exact = nullptr;
+    uint4*   mat = nullptr;
+    bool     have_scene = false, have_camera = false;
+    rtx_camera cam{};
+    // frame
+    uint32_t cols = 0, rows = 0;
+    float*   accum = nullptr;  size_t accum_floats = 0;
+    float4*  partials = nullptr; size_t partials_items = 0;
+    uint32_t* primary = nullptr; size_t primary_items = 0;
+    uint32_t* fb = nullptr; size_t fb_items = 0;
+    uint32_t* work_counter = nullptr;
+    unsigned long long* stats = nullptr;
+};
+
+extern "C" const char* rtx_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* rtx_version(void) { return "raytracing_amd 0.1 (gfx950)"; }
+
+extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
+{
+    if (!out_ctx) return fail(RTX_ERR_ARG, "rtx_create: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RTX_ERR_DEVICE, "rtx_create: no HIP device is visible (this library has no CPU path)");
+    if (device_id < 0 || device_id >= count) return fail(RTX_ERR_ARG, "rtx_create: device %d out of range (0..%d)", device_id, count - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(RTX_ERR_DEVICE, "rtx_create: device %d is %s; the kernels are built for gfx950 only", device_id, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+    rtx_ctx* c = new (std::nothrow) rtx_ctx();
+    if (!c) return fail(RTX_ERR_NOMEM, "rtx_create: out of host memory");
+    c->device = device_id;
+    c->num_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_first);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_last);
+    if (e == hipSuccess) e = hipMalloc(&c->work_counter, 256);
+    if (e == hipSuccess) e = hipMalloc(&c->stats, kStCount * sizeof(unsigned long long));
+    if (e != hipSuccess) { rtx_destroy(c); return fail(RTX_ERR_DEVICE, "rtx_create: %s", hipGetErrorString(e)); }
+    *out_ctx = c;
+    return RTX_OK;
+}
+
+extern "C" int rtx_destroy(rtx_ctx* c)
+{
+    if (!c) return RTX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = { c->hot, c->exact, c->mat, c->accum, c->partials, c->primary, c->fb, c->work_counter, c->stats };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->ev_first) (void)hipEventDestroy(c->ev_first);
+    if (c->ev_last) (void)hipEventDestroy(c->ev_last);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RTX_OK;
+}
+
+extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius,
+                                const uint32_t* mat_type, const float* ar, const float* ag, const float* ab, const float* blur, const float* ior)
+{
+    if (!c) return fail(RTX_ERR_ARG, "rtx_upload_scene: ctx is NULL");
+    if (n > 0 && (!cx || !cy || !cz || !radius || !mat_type || !ar || !ag || !ab || !blur || !ior)) return fail(RTX_ERR_ARG, "rtx_upload_scene: NULL array with n = %u", n);
+    if (n > (1u << 24)) return fail(RTX_ERR_ARG, "rtx_upload_scene: n = %u exceeds the supported 2^24 spheres", n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (mat_type[i] < RTX_MATERIAL_DIFFUSE || mat_type[i] > RTX_MATERIAL_GLASS)
+            return fail(RTX_ERR_ARG, "rtx_upload_scene: sphere %u has unknown material type %u (material.cu:34-36 asserts on it)", i, mat_type[i]);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n_pad = (n + 31u) & ~31u;
+    std::vector<float4> hot(n_pad), exact(std::max<uint32_t>(n, 1u));
+    std::vector<uint4>  mat(std::max<uint32_t>(2 * n, 2u));
+    for (uint32_t i = 0; i < n_pad; ++i) {
+        if (i < n) {
+            // the filter sees r^2 inflated by (1 + eps); products in double so that the inflation is not lost to rounding
+            const double r2 = (double)radius[i] * (double)radius[i] * (1.0 + (double)kEps);
+            hot[i] = make_float4(cx[i], cy[i], cz[i], -(float)std::nextafter((float)r2, INFINITY));
+            exact[i] = make_float4(cx[i], cy[i], cz[i], radius[i]);
+            uint32_t w[6];
+            memcpy(&w[0], &ar[i], 4); memcpy(&w[1], &ag[i], 4); memcpy(&w[2], &ab[i], 4); memcpy(&w[3], &blur[i], 4); memcpy(&w[4], &ior[i], 4);
+            mat[2 * i]     = make_uint4(mat_type[i], w[0], w[1], w[2]);
+            mat[2 * i + 1] = make_uint4(w[3], w[4], 0u, 0u);
+        } else {
+            hot[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0e30f);   // padding: never a candidate
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->hot) (void)hipFree(c->hot);
+    if (c->exact) (void)hipFree(c->exact);
+    if (c->mat) (void)hipFree(c->mat);
+    c->hot = nullptr; c->exact = nullptr; c->mat = nullptr; c->have_scene = false;
+    HIP_TRY(hipMalloc(&c->hot, std::max<size_t>(n_pad, 32) * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->exact, exact.size() * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->mat, mat.size() * sizeof(uint4)));
+    if (n_pad) HIP_TRY(hipMemcpy(c->hot, hot.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->exact, exact.data(), exact.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->mat, mat.data(), mat.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    c->n = n; c->n_pad = n_pad; c->have_scene = true;
+    return RTX_OK;
+}
+
+extern "C" int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam)
+{
+    if (!c || !cam) return fail(RTX_ERR_ARG, "rtx_set_camera: NULL argument");
+    c->cam = *cam;
+    c->have_camera = true;
+    return RTX_OK;
+}
+
+template <typename T> static int ensure(T** buf, size_t* have, size_t want)
+{
+    if (*have >= want && *buf) return RTX_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *have = 0;
+    hipError_t e = hipMalloc(buf, want * sizeof(T));
+    if (e != hipSuccess) return fail(RTX_ERR_NOMEM, "device allocation of %zu bytes failed: %s", want * sizeof(T), hipGetErrorString(e));
+    *have = want;
+    return RTX_OK;
+}
+
+static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                          uint64_t seed, uint32_t flags, uint32_t chunk_spp, bool want_primary, bool want_stats)
+{
+    if (!c) return fail(RTX_ERR_ARG, "rtx_render: ctx is NULL");
+    if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "rtx_render: upload a scene and a camera first");
+    if (cols == 0 || rows == 0 || spp_count == 0) return fail(RTX_ERR_ARG, "rtx_render: cols, rows and spp_count must be non-zero");
+    if ((uint64_t)cols * rows > (1ull << 28)) return fail(RTX_ERR_ARG, "rtx_render: image of %u x %u exceeds 2^28 pixels", cols, rows);
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_ARG, "rtx_render: sample range overflows 32 bits");
+    if (flags & RTX_FLAG_RECURSIVE) return fail(RTX_ERR_ARG, "rtx_render: RTX_FLAG_RECURSIVE (-r) is not implemented by the HIP backend yet");
+    if (flags & ~(uint32_t)(RTX_FLAG_ACCUMULATE | RTX_FLAG_RECURSIVE)) return fail(RTX_ERR_ARG, "rtx_render: unknown flag bits 0x%x", flags);
+    HIP_TRY(hipSetDevice(c->device));
+
+    const uint32_t npix = cols * rows;
+    const bool     accumulate = (flags & RTX_FLAG_ACCUMULATE) != 0;
+    if (accumulate && (c->cols != cols || c->rows != rows || !c->accum)) return fail(RTX_ERR_STATE, "rtx_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
+    if (c->cols != cols || c->rows != rows) { HIP_TRY(hipStreamSynchronize(c->stream)); }
+    int rc = ensure(&c->accum, &c->accum_floats, (size_t)npix * 3);
+    if (rc) return rc;
+    c->cols = cols; c->rows = rows;
+
+    if (!c->ev_open) { HIP_TRY(hipEventRecord(c->ev_first, c->stream)); c->ev_open = true; }
+
+    if (max_depth == 0) {
+        // raytracer.cpp:250: the bounce loop does not run, _color returns (1,1,1) for every sample
+        launch_fill(c->accum, npix * 3, (float)spp_count, accumulate, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_last, c->stream));
+        if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, kStCount * sizeof(unsigned long long), c->stream));
+        return RTX_OK;
+    }
+
+    const bool   lds_table = c->n_pad <= kMaxLdsSpheres;
+    const size_t lds_bytes = trace_lds_bytes(lds_table, c->n_pad);
+    const int    occ       = trace_occupancy(lds_table, lds_bytes);
+    const uint32_t max_grid = (uint32_t)c->num_cu * (uint32_t)occ;
+    const uint64_t lanes    = (uint64_t)max_grid * kBlock;
+
+    // sample chunking: enough work items for dynamic balance and a short tail, few enough to keep the partial
+    // buffer small.  One chunk reproduces the reference's summation order exactly.
+    if (chunk_spp == 0) {
+        uint64_t want_items = lanes * 32;
+        uint64_t nch = (want_items + npix - 1) / npix;
+        nch = std::max<uint64_t>(1, std::min<uint64_t>(nch, std::min<uint64_t>(spp_count, 64)));
+        chunk_spp = (uint32_t)((spp_count + nch - 1) / nch);
+    }
+    if (chunk_spp > spp_count) chunk_spp = spp_count;
+    const uint32_t nchunks = (spp_count + chunk_spp - 1) / chunk_spp;
+    const uint64_t n_items64 = (uint64_t)npix * nchunks;
+    if (n_items64 >= (1ull << 31)) return fail(RTX_ERR_ARG, "rtx_render: %llu work items; raise chunk_spp", (unsigned long long)n_items64);
+    const uint32_t n_items = (uint32_t)n_items64;
+    rc = ensure(&c->partials, &c->partials_items, (size_t)n_items);
+    if (rc) return rc;
+    if (want_primary) {
+        rc = ensure(&c->primary, &c->primary_items, (size_t)npix * spp_count);
+        if (rc) return rc;
+    }
+
+    TraceParams P{};
+    P.hot = c->hot; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
+    P.cols = cols; P.rows = rows; P.npix = npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = nchunks;
+    P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = n_items;
+    P.partials = c->partials; P.primary = want_primary ? c->primary : nullptr; P.work_counter = c->work_counter;
+    P.stats = want_stats ? c->stats : nullptr;
+
+    HIP_TRY(hipMemsetAsync(c->work_counter, 0, 256, c->stream));
+    if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, kStCount * sizeof(unsigned long long), c->stream));
+    const uint32_t blocks_needed = (uint32_t)((n_items64 + kBlock - 1) / kBlock);
+    const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(max_grid, blocks_needed));
+    launch_trace(P, lds_table, grid, lds_bytes, c->stream);
+    HIP_TRY(hipGetLastError());
+    launch_reduce(c->partials, c->accum, npix, nchunks, accumulate, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_last, c->stream));
+    return RTX_OK;
+}
+
+extern "C" int rtx_sync(rtx_ctx* c)
+{
+    if (!c) return fail(RTX_ERR_ARG, "rtx_sync: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+extern "C" int rtx_last_kernel_ms(rtx_ctx* c, double* ms)
+{
+    if (!c || !ms) return fail(RTX_ERR_ARG, "rtx_last_kernel_ms: NULL argument");
+    *ms = 0.0;
+    if (!c->ev_open) return RTX_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float f = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&f, c->ev_first, c->ev_last));
+    *ms = f;
+    c->ev_open = false;
+    return RTX_OK;
+}
+
+extern "C" int rtx_render_async(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                                uint64_t seed, uint32_t flags, uint32_t chunk_spp)
+{
+    return enqueue_render(c, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, false, false);
+}
+
+extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                          uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint32_t* primary_hit_host, rtx_stats* stats)
+{
+    if (c && c->ev_open) { double dummy; int rc0 = rtx_last_kernel_ms(c, &dummy); if (rc0) return rc0; }
+    int rc = enqueue_render(c, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, primary_hit_host != nullptr, stats != nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double ms = 0.0;
+    rc = rtx_last_kernel_ms(c, &ms);
+    if (rc) return rc;
+    if (primary_hit_host) {
+        if (max_depth == 0) memset(primary_hit_host, 0xFF, (size_t)cols * rows * spp_count * sizeof(uint32_t));
+        else HIP_TRY(hipMemcpy(primary_hit_host, c->primary, (size_t)cols * rows * spp_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    if (stats) {
+        unsigned long long h[kStCount];
+        HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
+        memset(stats, 0, sizeof(*stats));
+        if (max_depth == 0) {
+            stats->samples = (uint64_t)cols * rows * spp_count;
+            stats->term_depth = stats->samples;
+        } else {
+            stats->samples = h[kStSamples]; stats->rays = h[kStRays]; stats->sphere_tests = h[kStRays] * (uint64_t)c->n;
+            stats->term_miss = h[kStMiss]; stats->term_absorb = h[kStAbsorb]; stats->term_depth = h[kStDepth]; stats->candidates = h[kStCandidates];
+        }
+        stats->kernel_ms = ms;
+    }
+    return RTX_OK;
+}
+
+extern "C" int rtx_accum_device(rtx_ctx* c, float** accum_dev, size_t* n_floats)
+{
+    if (!c || !accum_dev || !n_floats) return fail(RTX_ERR_ARG, "rtx_accum_device: NULL argument");
+    if (!c->accum || c->cols == 0) return fail(RTX_ERR_STATE, "rtx_accum_device: nothing rendered yet");
+    *accum_dev = c->accum;
+    *n_floats  = (size_t)c->cols * c->rows * 3;
+    return RTX_OK;
+}
+
+extern "C" int rtx_read_accum(rtx_ctx* c, float* rgb_host, size_t n_floats)
+{
+    if (!c || !rgb_host) return fail(RTX_ERR_ARG, "rtx_read_accum: NULL argument");
+    if (!c->accum || n_floats != (size_t)c->cols * c->rows * 3) return fail(RTX_ERR_ARG, "rtx_read_accum: expected %zu floats", (size_t)c->cols * c->rows * 3);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(rgb_host, c->accum, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+extern "C" int rtx_write_accum(rtx_ctx* c, uint32_t cols, uint32_t rows, const float* rgb_host, size_t n_floats)
+{
+    if (!c || !rgb_host) return fail(RTX_ERR_ARG, "rtx_write_accum: NULL argument");
+    if (cols == 0 || rows == 0 || n_floats != (size_t)cols * rows * 3) return fail(RTX_ERR_ARG, "rtx_write_accum: size mismatch");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = ensure(&c->accum, &c->accum_floats, n_floats);
+    if (rc) return rc;
+    c->cols = cols; c->rows = rows;
+    HIP_TRY(hipMemcpy(c->accum, rgb_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    return RTX_OK;
+}
+
+extern "C" int rtx_resolve_rgbx8(rtx_ctx* c, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host)
+{
+    if (!c || !framebuffer_host) return fail(RTX_ERR_ARG, "rtx_resolve_rgbx8: NULL argument");
+    if (!c->accum || c->cols == 0) return fail(RTX_ERR_STATE, "rtx_resolve_rgbx8: nothing rendered yet");
+    if (spp_total == 0) return fail(RTX_ERR_ARG, "rtx_resolve_rgbx8: spp_total is 0");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)c->cols * c->rows;
+    int rc = ensure(&c->fb, &c->fb_items, npix);
+    if (rc) return rc;
+    launch_resolve(c->accum, c->fb, c->cols, c->rows, spp_total, debug_tile, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(framebuffer_host, c->fb, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}

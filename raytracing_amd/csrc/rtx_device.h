@@ -1,0 +1,47 @@
+// rtx_device.h -- shared declarations of the trace kernels (device side) and the C-ABI host code.
+#pragma once
+
+#include "../../include/rtx.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtx
+{
+
+// Tuning constants of the candidate filter ("conservative filter + exact re-test").
+// The filter works on the inflated quantities r^2 (1 + kEps) and h^2 (1 + kEps)^2; kEps = 2^-17 = 128 ulp covers
+// the <= 34 ulp that the reference's own rounding of b*b - a*c can move the sign of the discriminant.
+constexpr float    kEps        = 7.62939453125e-06f;  // 2^-17
+constexpr uint32_t kBlock      = 256;                  // threads per workgroup: 4 waves, one per SIMD
+constexpr uint32_t kWaveBatch  = 256;                  // work items a wave reserves per trip to the global counter
+constexpr uint32_t kListCap    = 16;                   // per-lane candidate list entries (LDS), flushed when full
+constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
+constexpr uint32_t kMaxLdsSpheres = 4096;              // hot table stays LDS-resident up to this many spheres
+
+enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStCount };
+
+struct TraceParams {
+    const float4* hot;      // n_pad x (cx, cy, cz, -(r^2 (1+eps)))  -- the filter's view of a sphere
+    const float4* exact;    // n x (cx, cy, cz, r)                   -- sphere.h:24-28 geometry, as uploaded
+    const uint4*  mat;      // 2n: [2i] = (type, albedo r, g, b), [2i+1] = (blur, ior, 0, 0), float bits
+    uint32_t      n, n_pad;
+    rtx_camera    cam;
+    uint32_t      cols, rows, npix;
+    uint32_t      spp_begin, spp_count, chunk_spp, nchunks;
+    uint32_t      max_depth, key0, key1, flags;
+    uint32_t      n_items;
+    float4*       partials;   // n_items x (sum r, g, b, 0): item = chunk * npix + pixel
+    uint32_t*     primary;    // NULL or spp_count * npix
+    uint32_t*     work_counter;
+    unsigned long long* stats; // kStCount counters
+};
+
+void launch_trace(const TraceParams& p, bool lds_table, uint32_t grid, size_t lds_bytes, hipStream_t stream);
+int  trace_occupancy(bool lds_table, size_t lds_bytes);
+size_t trace_lds_bytes(bool lds_table, uint32_t n_pad);
+void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream);
+void launch_fill(float* accum, uint32_t n_floats, float value, bool accumulate, hipStream_t stream);
+void launch_resolve(const float* accum, uint32_t* fb, uint32_t cols, uint32_t rows, uint32_t spp_total, uint32_t debug_tile, hipStream_t stream);
+
+} // namespace rtx

@@ -1,0 +1,123 @@
+// rtx_host.cpp -- host-only entry points of include/rtx.h: camera derivation, the seeded book-1 scene generator
+// and the PPM writer.  None of them touches a GPU.  Compiled with contraction off: the camera must come out
+// bit-identical to what the reference's Camera constructor (camera.h:20-41) computes with the same arguments.
+#include "../../include/rtx.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace
+{
+struct H3 { float x, y, z; };
+inline H3    h3(float x, float y, float z) { return H3{ x, y, z }; }
+inline H3    operator-(H3 a, H3 b) { return h3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline H3    operator*(float t, H3 v) { return h3(t * v.x, t * v.y, t * v.z); }
+inline H3    cross(H3 a, H3 b) { return h3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // vector_cuda.h:61-66
+inline H3    unit(H3 v) { float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); return h3(v.x / l, v.y / l, v.z / l); } // vector_cuda.h:53-59
+inline void  st3(float* d, H3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+// Philox4x32-10, the generator shared with the kernels (trace_kernel.hip) -- here it drives the scene layout.
+void philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct SceneDraws {
+    uint32_t key[2];
+    uint32_t n = 0;
+    float    next()
+    {
+        uint32_t ctr[4] = { n >> 2, 0u, 0u, 0x5CE9Eu }, r[4];
+        philox(ctr, key, r);
+        return (float)(r[n++ & 3u] >> 8) * (1.0f / 16777216.0f);
+    }
+};
+} // namespace
+
+extern "C" int rtx_camera_init(rtx_camera* cam, float vfov, float aspect, float aperture, float focus, const float pos[3], const float up[3], const float lookat[3])
+{
+    if (!cam || !pos || !up || !lookat) return RTX_ERR_ARG;
+    const float pi = 3.14159265358979323846f;                 // utils.h:70, a float literal
+    cam->lens_radius = aperture / 2.0f;                       // camera.h:28
+    float theta      = vfov * pi / 180.0f;                    // camera.h:30
+    float halfHeight = tanf(theta / 2);                       // camera.h:31
+    float halfWidth  = aspect * halfHeight;
+    H3 origin = h3(pos[0], pos[1], pos[2]);
+    H3 w = unit(origin - h3(lookat[0], lookat[1], lookat[2])); // camera.h:35-37
+    H3 u = unit(cross(h3(up[0], up[1], up[2]), w));
+    H3 v = cross(w, u);
+    H3 lc = origin - (halfWidth * focus) * u - (halfHeight * focus) * v - focus * w;   // camera.h:39
+    st3(cam->origin, origin);
+    st3(cam->left_corner, lc);
+    st3(cam->horizontal, (2 * halfWidth * focus) * u);        // camera.h:40
+    st3(cam->vertical, (2 * halfHeight * focus) * v);         // camera.h:41
+    st3(cam->u, u); st3(cam->v, v); st3(cam->w, w);
+    return RTX_OK;
+}
+
+extern "C" uint32_t rtx_scene_capacity(int grid_half) { return grid_half < 0 ? 4u : (uint32_t)(4 * grid_half * grid_half + 4); }
+
+extern "C" int rtx_random_scene(uint64_t seed, int grid_half, float p_diffuse, float p_metal, uint32_t* n_out,
+                                float* cx, float* cy, float* cz, float* radius, uint32_t* mat_type,
+                                float* ar, float* ag, float* ab, float* blur, float* ior)
+{
+    if (!n_out || !cx || !cy || !cz || !radius || !mat_type || !ar || !ag || !ab || !blur || !ior || grid_half < 0) return RTX_ERR_ARG;
+    SceneDraws g;
+    g.key[0] = (uint32_t)seed; g.key[1] = (uint32_t)(seed >> 32);
+    uint32_t n = 0;
+    auto push = [&](float x, float y, float z, float r, uint32_t type, float a0, float a1, float a2, float bl, float io) {
+        cx[n] = x; cy[n] = y; cz[n] = z; radius[n] = r; mat_type[n] = type; ar[n] = a0; ag[n] = a1; ab[n] = a2; blur[n] = bl; ior[n] = io; n++;
+    };
+    push(0, -1000.0f, 0, 1000, RTX_MATERIAL_DIFFUSE, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f);              // RayTracing.cpp:186
+    for (int a = -grid_half; a < grid_half; a++) {
+        for (int b = -grid_half; b < grid_half; b++) {                                            // :188-203
+            float material = g.next();
+            float x = a + 0.9f * g.next();
+            float z = b + 0.9f * g.next();
+            H3    dlt = h3(x, 0.2f, z) - h3(4.0f, 0.2f, 0.0f);
+            if (sqrtf(dlt.x * dlt.x + dlt.y * dlt.y + dlt.z * dlt.z) > 0.9f) {
+                if (material < p_diffuse) {
+                    float r0 = g.next(), r1 = g.next(), g0 = g.next(), g1 = g.next(), b0 = g.next(), b1 = g.next();
+                    push(x, 0.2f, z, 0.2f, RTX_MATERIAL_DIFFUSE, r0 * r1, g0 * g1, b0 * b1, 1.0f, 1.0f);
+                } else if (material > p_metal) {
+                    float r0 = g.next(), g0 = g.next(), b0 = g.next(), bl = g.next();
+                    push(x, 0.2f, z, 0.2f, RTX_MATERIAL_METAL, 0.5f * (1 + r0), 0.5f * (1 + g0), 0.5f * (1 + b0), 0.5f * bl, 1.0f);
+                } else {
+                    push(x, 0.2f, z, 0.2f, RTX_MATERIAL_GLASS, 1, 1, 1, 1.0f, 1.5f);
+                }
+            }
+        }
+    }
+    push(-4, 1, 0, 1.0f, RTX_MATERIAL_DIFFUSE, 0.4f, 0.2f, 0.1f, 1.0f, 1.0f);                      // :205-207
+    push(0, 1, 0, 1.0f, RTX_MATERIAL_GLASS, 0.4f, 0.2f, 0.1f, 1.0f, 1.5f);
+    push(4, 1, 0, 1.0f, RTX_MATERIAL_METAL, 0.7f, 0.6f, 0.5f, 0.0f, 1.0f);
+    *n_out = n;
+    return RTX_OK;
+}
+
+extern "C" int rtx_write_ppm(const char* path, uint32_t cols, uint32_t rows, const uint32_t* fb)
+{
+    if (!path || !fb) return RTX_ERR_ARG;
+    FILE* f = fopen(path, "w");
+    if (!f) return RTX_ERR_ARG;
+    fprintf(f, "P3\n");
+    fprintf(f, "%d %d\n", (int)cols, (int)rows);
+    fprintf(f, "255\n");
+    for (uint32_t y = 0; y < rows; y++) {
+        for (uint32_t x = 0; x < cols; x++) {
+            uint32_t rgb = fb[(size_t)y * cols + x];
+            fprintf(f, "%d %d %d\n", (int)((rgb >> 24) & 0xFF), (int)((rgb >> 16) & 0xFF), (int)((rgb >> 8) & 0xFF));
+        }
+    }
+    fflush(f);
+    fclose(f);
+    return RTX_OK;
+}
