@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the trace loop: book-1 final scene, 1200x800, 500 spp per GPU, depth 50.
+
+One step = one full render of that frame by every rank (weak scaling: each rank traces its own 500-sample range of
+every pixel; for N > 1 the accumulation buffers are summed with one RCCL all-reduce per step and rank 0 resolves to
+8 bits).  Inputs (sphere table, camera) are resident in HBM before the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (metric Msamples/s; Mrays/s, the FP32-VALU roofline of the trace kernel and the CPU
+baseline ride in the same object).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+COLS, ROWS, DEPTH, SEED = 1200, 800, 50, 1
+FP32_PEAK_TFLOPS = 157.3          # MI355X vector FP32 (MI355X_MICROARCH.md): 256 CU x 2.4 GHz x 256 flop/clk
+FLOP_PER_TEST = 18                # sphere.cpp:72-77 with a = d.d hoisted
+
+
+def cpu_baseline(table, seconds_budget=15.0):
+    """The oracle (a port of the reference CPU path: 40-byte AoS spheres, 64x64 tile jobs, iterative colour) timed on
+    this box's host cores on a bounded sample of the same workload: the full 1200x800 frame at `spp` samples."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    cores = max(1, min(16, os.cpu_count() or 1))
+    cam = pyoracle.book_camera(COLS, ROWS)
+    # calibrate on a strip, then size the sample to the budget
+    t0 = time.perf_counter()
+    pyoracle.render(table, cam, 40, COLS, 0, 1, DEPTH, SEED, nthreads=cores, tile=40)
+    strip = time.perf_counter() - t0
+    per_frame_spp = strip * (ROWS / 40.0)
+    spp = int(max(1, min(64, seconds_budget // max(per_frame_spp, 1e-3))))
+    t0 = time.perf_counter()
+    _, _, st = pyoracle.render(table, cam, ROWS, COLS, 0, spp, DEPTH, SEED, nthreads=cores, tile=64)
+    dt = time.perf_counter() - t0
+    return {"value": round(st["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "mrays_per_s": round(st["rays"] / dt / 1e6, 4),
+            "sample": "book1 %dx%d, %d spp, depth %d, 64x64 tile jobs on %d threads (%.1f s)" % (COLS, ROWS, spp, DEPTH, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=500, help="samples per pixel per GPU")
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--chunk-spp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    import raytracing_amd as ra
+    from raytracing_amd.multi_gpu import TorchAccum
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cols, rows, spp = args.cols, args.rows, args.spp
+    table = ra.random_scene(SEED)
+    ctx = ra.Context(local_rank)
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    accum = TorchAccum(ctx, cols, rows, torch.device("cuda", local_rank))
+    spp_begin = rank * spp                       # weak scaling: rank r owns global samples [r*spp, (r+1)*spp)
+
+    def step():
+        ctx.render_async(cols, rows, spp_begin, spp, DEPTH, SEED, 0, args.chunk_spp)
+        if world > 1:
+            accum.allreduce()
+        if rank == 0:
+            ctx.resolve(spp * world)
+        else:
+            ctx.sync()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    # one instrumented render: in-kernel ray / termination counters (the work of every later step is identical)
+    _, stats = ctx.render(cols, rows, spp_begin, spp, DEPTH, SEED, 0, args.chunk_spp, want_stats=True)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    trace_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        trace_ms.append(ctx.last_trace_ms())     # HIP events around the trace kernel, on the stream it ran on
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([float(stats["rays"]), float(stats["samples"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        rays_all, samples_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        rays_all, samples_all = float(stats["rays"]), float(stats["samples"])
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        trace_avg_ms = sum(trace_ms) / len(trace_ms)
+        tests = stats["sphere_tests"]
+        achieved = FLOP_PER_TEST * tests / (trace_avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/s", "value": round(samples_all / (dt / args.steps) / 1e6, 3), "unit": "Msamples/s",
+            "mrays_per_s": round(rays_all / (dt / args.steps) / 1e6, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "book-1 final scene (seed 1, %d spheres) %dx%d, %d spp per GPU, depth %d" % (len(table), cols, rows, spp, DEPTH),
+                       "parallelism": "spp split x%d + RCCL all-reduce of the float accumulation buffer" % world if world > 1 else "1 GPU",
+                       "rays_per_sample": round(stats["rays"] / stats["samples"], 4)},
+            "roofline": {"bound": "fp32-valu", "kernel": "trace_kernel", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(trace_avg_ms, 4), "sphere_tests_per_launch": tests, "flop_per_test": FLOP_PER_TEST,
+                         "exact_tests_per_launch": stats["candidates"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(table)
+        print(json.dumps(out))
+    accum.release()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,11 +113,18 @@ int rtx_sync(rtx_ctx* ctx);
 /* Milliseconds between the first and the last kernel enqueued since the previous rtx_sync (HIP events). */
 int rtx_last_kernel_ms(rtx_ctx* ctx, double* ms);
 
+/* Milliseconds the most recent trace kernel alone took (HIP events on the context's stream, around that launch). */
+int rtx_last_trace_ms(rtx_ctx* ctx, double* ms);
+
 /* ---- outputs --------------------------------------------------------------------------------------------- */
 
 /* The accumulation buffer in device memory (valid until the next rtx_render with another image size or
  * rtx_destroy).  The multi-GPU host sums these across ranks in place (RCCL all-reduce) before resolving. */
 int rtx_accum_device(rtx_ctx* ctx, float** accum_dev, size_t* n_floats);
+/* Makes the context accumulate into caller-owned device memory (cols*rows*3 floats on the context's GPU, e.g. a
+ * torch tensor's data_ptr) so that the host can hand the very same buffer to its collective library.  NULL returns
+ * to a library-owned buffer.  The reference's caller owns the framebuffer in the same way (RayTracing.cpp:123-129). */
+int rtx_use_accum_buffer(rtx_ctx* ctx, uint32_t cols, uint32_t rows, float* accum_dev);
 int rtx_read_accum(rtx_ctx* ctx, float* rgb_host, size_t n_floats);
 int rtx_write_accum(rtx_ctx* ctx, uint32_t cols, uint32_t rows, const float* rgb_host, size_t n_floats);
 

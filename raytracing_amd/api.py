@@ -12,7 +12,7 @@ FLAG_ACCUMULATE, FLAG_RECURSIVE = 1, 2
 
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_camera", "rtx_render",
-           "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
+           "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
            "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_version"]
 
 
@@ -59,6 +59,8 @@ def lib():
     L.rtx_render_async.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32]
     L.rtx_sync.argtypes = [C.c_void_p]
     L.rtx_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double)]
+    L.rtx_last_trace_ms.argtypes = [C.c_void_p, P(C.c_double)]
+    L.rtx_use_accum_buffer.argtypes = [C.c_void_p, u32, u32, C.c_void_p]
     L.rtx_accum_device.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t)]
     L.rtx_read_accum.argtypes = [C.c_void_p, fp, C.c_size_t]
     L.rtx_write_accum.argtypes = [C.c_void_p, u32, u32, fp, C.c_size_t]
@@ -212,6 +214,17 @@ class Context:
         ms = C.c_double(0)
         _check(lib().rtx_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def last_trace_ms(self):
+        ms = C.c_double(0)
+        _check(lib().rtx_last_trace_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def use_accum_buffer(self, cols, rows, dev_ptr):
+        """dev_ptr: integer device address of cols*rows*3 floats on this context's GPU (0/None: library-owned)."""
+        _check(lib().rtx_use_accum_buffer(self._h, cols, rows, C.c_void_p(dev_ptr or None)))
+        if dev_ptr:
+            self.cols, self.rows = cols, rows
 
     def accum_device(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -36,6 +36,8 @@ struct rtx_ctx {
     int         num_cu = 0;
     hipStream_t stream = nullptr;
     hipEvent_t  ev_first = nullptr, ev_last = nullptr;
+    hipEvent_t  ev_t0 = nullptr, ev_t1 = nullptr;   // around the most recent trace kernel
+    bool        ev_trace = false;
     bool        ev_open = false;      // ev_first recorded since the last sync
     // scene
     uint32_t n = 0, n_pad = 0;
@@ -47,6 +49,7 @@ struct rtx_ctx {
     // frame
     uint32_t cols = 0, rows = 0;
     float*   accum = nullptr;  size_t accum_floats = 0;
+    bool     accum_borrowed = false;   // caller-owned buffer (rtx_use_accum_buffer)
     float4*  partials = nullptr; size_t partials_items = 0;
     uint32_t* primary = nullptr; size_t primary_items = 0;
     uint32_t* fb = nullptr; size_t fb_items = 0;
@@ -75,6 +78,8 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_first);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_last);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
     if (e == hipSuccess) e = hipMalloc(&c->work_counter, 256);
     if (e == hipSuccess) e = hipMalloc(&c->stats, kStCount * sizeof(unsigned long long));
     if (e != hipSuccess) { rtx_destroy(c); return fail(RTX_ERR_DEVICE, "rtx_create: %s", hipGetErrorString(e)); }
@@ -87,10 +92,10 @@ extern "C" int rtx_destroy(rtx_ctx* c)
     if (!c) return RTX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->hot, c->exact, c->mat, c->accum, c->partials, c->primary, c->fb, c->work_counter, c->stats };
+    void* bufs[] = { c->hot, c->exact, c->mat, c->accum_borrowed ? nullptr : c->accum, c->partials, c->primary, c->fb, c->work_counter, c->stats };
     for (void* b : bufs) if (b) (void)hipFree(b);
-    if (c->ev_first) (void)hipEventDestroy(c->ev_first);
-    if (c->ev_last) (void)hipEventDestroy(c->ev_last);
+    hipEvent_t evs[] = { c->ev_first, c->ev_last, c->ev_t0, c->ev_t1 };
+    for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RTX_OK;
@@ -174,8 +179,13 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     const bool     accumulate = (flags & RTX_FLAG_ACCUMULATE) != 0;
     if (accumulate && (c->cols != cols || c->rows != rows || !c->accum)) return fail(RTX_ERR_STATE, "rtx_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
     if (c->cols != cols || c->rows != rows) { HIP_TRY(hipStreamSynchronize(c->stream)); }
-    int rc = ensure(&c->accum, &c->accum_floats, (size_t)npix * 3);
-    if (rc) return rc;
+    int rc = RTX_OK;
+    if (c->accum_borrowed) {
+        if (c->accum_floats != (size_t)npix * 3) return fail(RTX_ERR_STATE, "rtx_render: the caller's accumulation buffer holds %zu floats, this image needs %zu", c->accum_floats, (size_t)npix * 3);
+    } else {
+        rc = ensure(&c->accum, &c->accum_floats, (size_t)npix * 3);
+        if (rc) return rc;
+    }
     c->cols = cols; c->rows = rows;
 
     if (!c->ev_open) { HIP_TRY(hipEventRecord(c->ev_first, c->stream)); c->ev_open = true; }
@@ -226,8 +236,11 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, kStCount * sizeof(unsigned long long), c->stream));
     const uint32_t blocks_needed = (uint32_t)((n_items64 + kBlock - 1) / kBlock);
     const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(max_grid, blocks_needed));
+    HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
     launch_trace(P, lds_table, grid, lds_bytes, c->stream);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    c->ev_trace = true;
     launch_reduce(c->partials, c->accum, npix, nchunks, accumulate, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_last, c->stream));
@@ -252,6 +265,34 @@ extern "C" int rtx_last_kernel_ms(rtx_ctx* c, double* ms)
     HIP_TRY(hipEventElapsedTime(&f, c->ev_first, c->ev_last));
     *ms = f;
     c->ev_open = false;
+    return RTX_OK;
+}
+
+extern "C" int rtx_last_trace_ms(rtx_ctx* c, double* ms)
+{
+    if (!c || !ms) return fail(RTX_ERR_ARG, "rtx_last_trace_ms: NULL argument");
+    *ms = 0.0;
+    if (!c->ev_trace) return fail(RTX_ERR_STATE, "rtx_last_trace_ms: no trace kernel has been launched");
+    HIP_TRY(hipEventSynchronize(c->ev_t1));
+    float f = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&f, c->ev_t0, c->ev_t1));
+    *ms = f;
+    return RTX_OK;
+}
+
+extern "C" int rtx_use_accum_buffer(rtx_ctx* c, uint32_t cols, uint32_t rows, float* accum_dev)
+{
+    if (!c) return fail(RTX_ERR_ARG, "rtx_use_accum_buffer: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->accum_borrowed && c->accum) (void)hipFree(c->accum);
+    c->accum = nullptr; c->accum_floats = 0; c->accum_borrowed = false; c->cols = 0; c->rows = 0;
+    if (!accum_dev) return RTX_OK;                         // back to a library-owned buffer
+    if (cols == 0 || rows == 0) return fail(RTX_ERR_ARG, "rtx_use_accum_buffer: empty image");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, accum_dev) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != c->device)
+        return fail(RTX_ERR_ARG, "rtx_use_accum_buffer: pointer is not device memory of GPU %d", c->device);
+    c->accum = accum_dev; c->accum_floats = (size_t)cols * rows * 3; c->accum_borrowed = true; c->cols = cols; c->rows = rows;
     return RTX_OK;
 }
 
@@ -316,8 +357,12 @@ extern "C" int rtx_write_accum(rtx_ctx* c, uint32_t cols, uint32_t rows, const f
     if (cols == 0 || rows == 0 || n_floats != (size_t)cols * rows * 3) return fail(RTX_ERR_ARG, "rtx_write_accum: size mismatch");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    int rc = ensure(&c->accum, &c->accum_floats, n_floats);
-    if (rc) return rc;
+    if (c->accum_borrowed) {
+        if (c->accum_floats != n_floats) return fail(RTX_ERR_STATE, "rtx_write_accum: size differs from the caller's accumulation buffer");
+    } else {
+        int rc = ensure(&c->accum, &c->accum_floats, n_floats);
+        if (rc) return rc;
+    }
     c->cols = cols; c->rows = rows;
     HIP_TRY(hipMemcpy(c->accum, rgb_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
     return RTX_OK;
