@@ -1,0 +1,190 @@
+"""Edge cases and size-independent properties of the HIP path (through the C ABI).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import raytracing_amd
+    raytracing_amd.lib()
+    return raytracing_amd
+
+
+@pytest.fixture()
+def ctx(ra):
+    c = ra.Context(0)
+    yield c
+    c.close()
+
+
+def _both(ra, ctx, oracle, table, cols, rows, spp_begin, spp, depth, seed, chunk=0):
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    eff = chunk if chunk else spp
+    primary, st = ctx.render(cols, rows, spp_begin, spp, depth, seed, chunk_spp=eff, want_primary=True)
+    accum = ctx.read_accum()
+    o_accum, o_primary, o_st = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, spp_begin, spp, depth, seed, chunk_spp=eff, want_primary=True)
+    return accum, primary, st, o_accum, o_primary, o_st
+
+
+def test_empty_scene(ra, ctx, oracle):
+    """n = 0: every ray ends on the background (raytracer.cpp:266-269)."""
+    table = np.zeros((0, 10), dtype=np.float32)
+    accum, primary, st, o_accum, o_primary, o_st = _both(ra, ctx, oracle, table, 40, 30, 0, 3, 50, 1)
+    assert (primary == 0xFFFFFFFF).all() and (bits(accum) == bits(o_accum)).all()
+    assert st["rays"] == st["samples"] == st["term_miss"] == 40 * 30 * 3 and st["sphere_tests"] == 0
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 65])
+def test_ragged_table_sizes(ra, ctx, oracle, golden_scenes, n):
+    """Sphere counts around the 32-sphere filter block (padding must never hit)."""
+    book = golden_scenes["book1"]
+    table = np.concatenate([book[:max(0, n - 3)], book[-min(3, n):]])[:n] if n > 3 else book[-n:]
+    assert len(table) == n
+    accum, primary, st, o_accum, o_primary, o_st = _both(ra, ctx, oracle, table, 64, 40, 0, 2, 50, 3)
+    assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+    assert primary[primary != 0xFFFFFFFF].max(initial=0) < n
+
+
+def test_one_pixel_and_thin_images(ra, ctx, oracle, golden_scenes):
+    for cols, rows in [(1, 1), (1, 17), (257, 1), (3, 2)]:
+        accum, primary, st, o_accum, o_primary, _ = _both(ra, ctx, oracle, golden_scenes["book1"], cols, rows, 0, 5, 50, 4)
+        assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+
+
+def test_large_table_streams_from_l2(ra, ctx, oracle):
+    """More spheres than the LDS-resident limit: the filter reads the table through L2 instead (BASELINE config 5 path)."""
+    table = ra.random_scene(1, grid_half=36)          # ~5.1k spheres > 4096
+    assert len(table) > 4096
+    accum, primary, st, o_accum, o_primary, o_st = _both(ra, ctx, oracle, table, 40, 24, 0, 1, 50, 2)
+    assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+    assert st["rays"] == o_st["rays"]
+
+
+def test_glass_heavy_scene(ra, ctx, oracle, golden_scenes):
+    """BASELINE config 4: mostly dielectric spheres, long paths, refraction branches."""
+    accum, primary, st, o_accum, o_primary, o_st = _both(ra, ctx, oracle, golden_scenes["glass"], 80, 60, 0, 4, 50, 6, chunk=2)
+    assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+    for k in ("rays", "term_miss", "term_absorb", "term_depth"):
+        assert st[k] == o_st[k]
+    assert st["rays"] / st["samples"] > 3.0
+
+
+def test_depth_zero_and_one(ra, ctx, oracle, golden_scenes):
+    table = golden_scenes["book1"]
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(20, 10))
+    _, st = ctx.render(20, 10, 0, 3, 0, 1)
+    assert (ctx.read_accum() == 3.0).all() and st["rays"] == 0          # the loop of raytracer.cpp:250 never runs
+    assert (ctx.resolve(3) == 0xFFFFFF00).all()
+    accum, primary, st, o_accum, o_primary, o_st = _both(ra, ctx, oracle, table, 20, 10, 0, 3, 1, 1)
+    assert (bits(accum) == bits(o_accum)).all() and st["rays"] == st["samples"]
+
+
+def test_sample_ranges_add_up(ra, ctx, golden_scenes):
+    """Rendering [0,a) then accumulating [a,b) equals rendering [0,b) with chunk a (same summation order)."""
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(60, 40))
+    ctx.render(60, 40, 0, 8, 50, 11, chunk_spp=4)
+    whole = ctx.read_accum()
+    ctx.render(60, 40, 0, 4, 50, 11, chunk_spp=4)
+    ctx.render(60, 40, 4, 4, 50, 11, flags=ra.FLAG_ACCUMULATE, chunk_spp=4)
+    assert (bits(ctx.read_accum()) == bits(whole)).all()
+
+
+def test_deterministic_and_chunking_invariant_primary(ra, ctx, golden_scenes):
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(200, 120))
+    p1, s1 = ctx.render(200, 120, 0, 6, 50, 5, chunk_spp=6, want_primary=True)
+    a1 = ctx.read_accum()
+    p2, s2 = ctx.render(200, 120, 0, 6, 50, 5, chunk_spp=6, want_primary=True)
+    assert (bits(a1) == bits(ctx.read_accum())).all() and (p1 == p2).all()
+    p3, s3 = ctx.render(200, 120, 0, 6, 50, 5, chunk_spp=1, want_primary=True)
+    a3 = ctx.read_accum()
+    assert (p1 == p3).all() and np.allclose(a1, a3, rtol=1e-5, atol=1e-6)
+    for k in ("rays", "samples", "term_miss", "term_absorb", "term_depth"):
+        assert s1[k] == s2[k] == s3[k]
+    p4, _ = ctx.render(200, 120, 0, 6, 50, 6, chunk_spp=6, want_primary=True)
+    assert (p1 != p4).any()                                            # another seed, another sample set
+
+
+def test_debug_borders_and_resolve(ra, ctx, oracle, golden_scenes):
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(130, 70))
+    ctx.render(130, 70, 0, 2, 50, 1, chunk_spp=2)
+    accum = ctx.read_accum()
+    assert (ctx.resolve(2, debug_tile=64) == oracle.resolve(accum, 70, 130, 2, debug_tile=64)).all()
+    assert (ctx.resolve(2) == oracle.resolve(accum, 70, 130, 2)).all()
+
+
+def test_write_accum_roundtrip_and_borrowed_buffer(ra, ctx, golden_scenes):
+    import torch
+    rng = np.random.default_rng(0)
+    a = rng.random(50 * 20 * 3, dtype=np.float32)
+    ctx.write_accum(50, 20, a)
+    assert (bits(ctx.read_accum()) == bits(a)).all()
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(50, 20))
+    ctx.render(50, 20, 0, 2, 50, 1, chunk_spp=2)
+    own = ctx.read_accum()
+    t = torch.zeros(50 * 20 * 3, dtype=torch.float32, device="cuda:0")
+    ctx.use_accum_buffer(50, 20, t.data_ptr())
+    ctx.render(50, 20, 0, 2, 50, 1, chunk_spp=2)
+    ctx.sync()
+    assert (bits(t.cpu().numpy()) == bits(own)).all()
+    with pytest.raises(ra.RtxError):
+        ctx.render(51, 20, 0, 2, 50, 1)                                 # the borrowed buffer has another size
+    ctx.use_accum_buffer(0, 0, 0)
+
+
+def test_argument_errors(ra, ctx, golden_scenes):
+    with pytest.raises(ra.RtxError, match="upload a scene"):
+        ctx.render(8, 8, 0, 1, 5, 1)
+    bad = golden_scenes["book1"].copy()
+    bad[3, 4] = 7
+    with pytest.raises(ra.RtxError, match="unknown material"):
+        ctx.upload_scene(bad)
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(8, 8))
+    with pytest.raises(ra.RtxError):
+        ctx.render(8, 8, 0, 0, 5, 1)
+    with pytest.raises(ra.RtxError):
+        ctx.render(0, 8, 0, 1, 5, 1)
+    with pytest.raises(ra.RtxError, match="ACCUMULATE"):
+        ctx.render(9, 9, 0, 1, 5, 1, flags=ra.FLAG_ACCUMULATE)
+    with pytest.raises(ra.RtxError):
+        ra.Context(99)
+
+
+def test_render_scene_hip_signature(ra, oracle, golden_scenes):
+    """The drop-in wrapper with renderScene's argument list (raytracer.h:17) fills the caller's framebuffer."""
+    table = golden_scenes["book1"]
+    fb = np.full(48 * 32, 0xCCCCCCCC, dtype=np.uint32)                  # RayTracing.cpp:128 pre-fills with 0xCC
+    rc = ra.render_scene_hip(ra.Scene.from_table(table), ra.book_camera(48, 32), 32, 48, fb, 2, 50, 1, 64, False, False, seed=5)
+    assert rc == 0
+    o_accum, _, _ = oracle.render(table, oracle.book_camera(48, 32), 32, 48, 0, 2, 50, 5)
+    assert (fb == oracle.resolve(o_accum, 32, 48, 2)).all()
+
+
+def test_full_size_properties(ra, ctx, golden_scenes):
+    """BASELINE's frame size, 1200x800: counters, split additivity and the image statistics at 4 spp."""
+    cols, rows, spp = 1200, 800, 4
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(cols, rows))
+    _, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=2)
+    whole = ctx.read_accum()
+    assert st["samples"] == cols * rows * spp
+    assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
+    assert st["sphere_tests"] == st["rays"] * 485
+    assert 2.6 < st["rays"] / st["samples"] < 2.9                       # 2.71 rays per sample
+    ctx.render(cols, rows, 0, 2, 50, 1, chunk_spp=2)
+    ctx.render(cols, rows, 2, 2, 50, 1, flags=ra.FLAG_ACCUMULATE, chunk_spp=2)
+    assert (bits(ctx.read_accum()) == bits(whole)).all()
+    assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() <= spp
+    fb = ctx.resolve(spp)
+    top = ((fb.reshape(rows, cols)[:40] >> 8) & 0xFF).mean()           # sky rows: blue channel near 255
+    assert top > 230 and (fb & 0xFF == 0).all()
