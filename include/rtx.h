@@ -53,8 +53,13 @@ typedef struct rtx_camera {
 /* rtx_render flags */
 enum {
     RTX_FLAG_ACCUMULATE = 1u << 0,  /* add this call's colour sums to the accumulation buffer instead of replacing it */
-    RTX_FLAG_RECURSIVE  = 1u << 1   /* the -r semantics of raytracer.cpp:213-240 (absorbed / over-depth paths are black) */
+    RTX_FLAG_RECURSIVE  = 1u << 1,  /* the -r semantics of raytracer.cpp:213-240 (absorbed / over-depth paths are black) */
+    RTX_FLAG_VALIDATE_FILTER = 1u << 2 /* debug: also run the reference's full ascending scan (raytracer.cpp:291-300) for
+                                       every ray and count disagreements with the filtered result in stats.filter_misses */
 };
+
+/* Candidate filters in front of the exact sphereHit arithmetic (results are identical; only speed differs). */
+enum { RTX_FILTER_VALU = 0, RTX_FILTER_MFMA = 1 };
 
 /* Counters gathered inside the kernel with wave ballots (rays = _sceneHit calls, raytracer.cpp:251). */
 typedef struct rtx_stats {
@@ -65,6 +70,7 @@ typedef struct rtx_stats {
     uint64_t term_absorb;       /* paths ended by materialScatter returning false (raytracer.cpp:262-264) */
     uint64_t term_depth;        /* paths that used up max_depth bounces (raytracer.cpp:250) */
     uint64_t candidates;        /* (ray, sphere) pairs that went through the exact sphereHit arithmetic */
+    uint64_t filter_misses;     /* RTX_FLAG_VALIDATE_FILTER only: rays whose filtered hit differs from the full scan (must be 0) */
     double   kernel_ms;         /* trace + reduce kernels, HIP events on the context's stream */
 } rtx_stats;
 
@@ -87,6 +93,10 @@ int rtx_upload_scene(rtx_ctx* ctx, uint32_t n,
                      const uint32_t* mat_type_host,
                      const float* albedo_r_host, const float* albedo_g_host, const float* albedo_b_host,
                      const float* blur_host, const float* ior_host);
+
+/* Chooses the candidate filter (default RTX_FILTER_MFMA; the environment variable RTX_FILTER=valu|mfma overrides the
+ * default at rtx_create).  No counterpart in the reference: both forms feed the same exact sphere.cpp:68-102 test. */
+int rtx_set_filter(rtx_ctx* ctx, int kind);
 
 /* Replaces raytracer.cu:68-73 (_createCamera) / raytracerispc.cpp:91-103 (cameraInitISPC). */
 int rtx_set_camera(rtx_ctx* ctx, const rtx_camera* cam);

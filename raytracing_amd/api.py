@@ -5,13 +5,15 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx.so")
+# RTX_LIB_PATH selects another build of the same library (A/B experiments); the default is the in-tree one.
+LIB_PATH = os.environ.get("RTX_LIB_PATH") or os.path.join(_HERE, "librtx.so")
 
 MATERIAL_NONE, MATERIAL_DIFFUSE, MATERIAL_METAL, MATERIAL_GLASS = 0, 1, 2, 3   # material.h:9-14
-FLAG_ACCUMULATE, FLAG_RECURSIVE = 1, 2
+FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER = 1, 2, 4
+FILTER_VALU, FILTER_MFMA = 0, 1
 
 # every symbol include/rtx.h declares
-EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_camera", "rtx_render",
+EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_camera", "rtx_render",
            "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
            "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_version"]
 
@@ -29,7 +31,7 @@ class CCamera(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64), ("term_miss", C.c_uint64),
-                ("term_absorb", C.c_uint64), ("term_depth", C.c_uint64), ("candidates", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("term_absorb", C.c_uint64), ("term_depth", C.c_uint64), ("candidates", C.c_uint64), ("filter_misses", C.c_uint64), ("kernel_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -54,6 +56,7 @@ def lib():
     L.rtx_create.argtypes = [C.c_int, P(C.c_void_p)]
     L.rtx_destroy.argtypes = [C.c_void_p]
     L.rtx_upload_scene.argtypes = [C.c_void_p, u32, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
+    L.rtx_set_filter.argtypes = [C.c_void_p, C.c_int]
     L.rtx_set_camera.argtypes = [C.c_void_p, P(CCamera)]
     L.rtx_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, up, P(Stats)]
     L.rtx_render_async.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32]
@@ -190,6 +193,9 @@ class Context:
         _check(lib().rtx_upload_scene(self._h, len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), _up(mt),
                                       _fp(cols[5]), _fp(cols[6]), _fp(cols[7]), _fp(cols[8]), _fp(cols[9])))
         self.n = len(t)
+
+    def set_filter(self, kind):
+        _check(lib().rtx_set_filter(self._h, kind))
 
     def set_camera(self, cam):
         c = cam.c if isinstance(cam, Camera) else cam

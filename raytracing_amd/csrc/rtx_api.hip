@@ -40,8 +40,10 @@ struct rtx_ctx {
     bool        ev_trace = false;
     bool        ev_open = false;      // ev_first recorded since the last sync
     // scene
-    uint32_t n = 0, n_pad = 0;
+    uint32_t n = 0, n_pad = 0, n_pad_mfma = 0;
+    int      filter = kFilterMfma;
     float4*  hot = nullptr;
+    float4*  hot_mfma = nullptr;
     float4*  exact = nullptr;
     uint4*   mat = nullptr;
     bool     have_scene = false, have_camera = false;
@@ -75,13 +77,14 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     if (!c) return fail(RTX_ERR_NOMEM, "rtx_create: out of host memory");
     c->device = device_id;
     c->num_cu = prop.multiProcessorCount;
+    if (const char* f = getenv("RTX_FILTER")) c->filter = (strcmp(f, "valu") == 0) ? kFilterValu : kFilterMfma;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_first);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_last);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
     if (e == hipSuccess) e = hipMalloc(&c->work_counter, 256);
-    if (e == hipSuccess) e = hipMalloc(&c->stats, kStCount * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->stats, (kStCount + 8) * sizeof(unsigned long long));
     if (e != hipSuccess) { rtx_destroy(c); return fail(RTX_ERR_DEVICE, "rtx_create: %s", hipGetErrorString(e)); }
     *out_ctx = c;
     return RTX_OK;
@@ -92,7 +95,7 @@ extern "C" int rtx_destroy(rtx_ctx* c)
     if (!c) return RTX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->hot, c->exact, c->mat, c->accum_borrowed ? nullptr : c->accum, c->partials, c->primary, c->fb, c->work_counter, c->stats };
+    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->accum_borrowed ? nullptr : c->accum, c->partials, c->primary, c->fb, c->work_counter, c->stats };
     for (void* b : bufs) if (b) (void)hipFree(b);
     hipEvent_t evs[] = { c->ev_first, c->ev_last, c->ev_t0, c->ev_t1 };
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -129,7 +132,41 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
             hot[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0e30f);   // padding: never a candidate
         }
     }
+    // MFMA filter: per 16-sphere tile, lane (g = lane >> 4, r = lane & 15) holds component g of sphere 16 t + r as the
+    // eight bf16 (s1,s1,s2,s1,s2,s3,s2,s3) of its exact three-way split; component 3 is K'' = |C|^2 - r^2 - margin.
+    const uint32_t n_pad_mfma = (n + 127u) & ~127u;
+    std::vector<uint4> tabA((size_t)std::max<uint32_t>(n_pad_mfma, 128u) * 4u);
+    auto split3 = [](float x, uint32_t h[3]) {
+        float rem = x;
+        for (int k = 0; k < 3; ++k) {
+            uint32_t u; memcpy(&u, &rem, 4); u &= 0xFFFF0000u;
+            float part; memcpy(&part, &u, 4);
+            h[k] = u >> 16;
+            rem -= part;                      // exact: part is the truncation of rem
+        }
+    };
+    for (uint32_t i = 0; i < n_pad_mfma; ++i) {
+        float comp[4] = { 0.0f, 0.0f, 0.0f, 1.0e30f };           // padding: c = 1e30 + ..., never negative
+        if (i < n) {
+            const double C2 = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
+            const double r2 = (double)radius[i] * radius[i];
+            const double Kp = C2 - r2;
+            const double Kpp = Kp - kGammaSphere * (C2 + r2 + std::fabs(Kp));
+            comp[0] = cx[i]; comp[1] = cy[i]; comp[2] = cz[i];
+            comp[3] = std::nextafter((float)Kpp, -INFINITY);       // rounded towards "more candidates"
+        }
+        const uint32_t t = i >> 4, r = i & 15u;
+        for (uint32_t g = 0; g < 4u; ++g) {
+            uint32_t h[3];
+            split3(comp[g], h);
+            tabA[(size_t)t * 64u + g * 16u + r] = make_uint4(h[0] | (h[0] << 16), h[1] | (h[0] << 16), h[1] | (h[2] << 16), h[1] | (h[2] << 16));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->hot_mfma) (void)hipFree(c->hot_mfma);
+    c->hot_mfma = nullptr;
+    HIP_TRY(hipMalloc(&c->hot_mfma, tabA.size() * sizeof(uint4)));
+    HIP_TRY(hipMemcpy(c->hot_mfma, tabA.data(), tabA.size() * sizeof(uint4), hipMemcpyHostToDevice));
     if (c->hot) (void)hipFree(c->hot);
     if (c->exact) (void)hipFree(c->exact);
     if (c->mat) (void)hipFree(c->mat);
@@ -140,7 +177,15 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     if (n_pad) HIP_TRY(hipMemcpy(c->hot, hot.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->exact, exact.data(), exact.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat, mat.data(), mat.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    c->n = n; c->n_pad = n_pad; c->have_scene = true;
+    c->n = n; c->n_pad = n_pad; c->n_pad_mfma = n_pad_mfma; c->have_scene = true;
+    return RTX_OK;
+}
+
+extern "C" int rtx_set_filter(rtx_ctx* c, int kind)
+{
+    if (!c) return fail(RTX_ERR_ARG, "rtx_set_filter: ctx is NULL");
+    if (kind != RTX_FILTER_VALU && kind != RTX_FILTER_MFMA) return fail(RTX_ERR_ARG, "rtx_set_filter: unknown filter %d", kind);
+    c->filter = kind;
     return RTX_OK;
 }
 
@@ -172,7 +217,7 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     if ((uint64_t)cols * rows > (1ull << 28)) return fail(RTX_ERR_ARG, "rtx_render: image of %u x %u exceeds 2^28 pixels", cols, rows);
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_ARG, "rtx_render: sample range overflows 32 bits");
     if (flags & RTX_FLAG_RECURSIVE) return fail(RTX_ERR_ARG, "rtx_render: RTX_FLAG_RECURSIVE (-r) is not implemented by the HIP backend yet");
-    if (flags & ~(uint32_t)(RTX_FLAG_ACCUMULATE | RTX_FLAG_RECURSIVE)) return fail(RTX_ERR_ARG, "rtx_render: unknown flag bits 0x%x", flags);
+    if (flags & ~(uint32_t)(RTX_FLAG_ACCUMULATE | RTX_FLAG_RECURSIVE | RTX_FLAG_VALIDATE_FILTER)) return fail(RTX_ERR_ARG, "rtx_render: unknown flag bits 0x%x", flags);
     HIP_TRY(hipSetDevice(c->device));
 
     const uint32_t npix = cols * rows;
@@ -195,13 +240,15 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         launch_fill(c->accum, npix * 3, (float)spp_count, accumulate, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_last, c->stream));
-        if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, kStCount * sizeof(unsigned long long), c->stream));
+        if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 8) * sizeof(unsigned long long), c->stream));
         return RTX_OK;
     }
 
-    const bool   lds_table = c->n_pad <= kMaxLdsSpheres;
-    const size_t lds_bytes = trace_lds_bytes(lds_table, c->n_pad);
-    const int    occ       = trace_occupancy(lds_table, lds_bytes);
+    const bool   validate  = (flags & RTX_FLAG_VALIDATE_FILTER) != 0;
+    const int    filter    = c->filter;
+    const bool   lds_table = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
+    const size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n_pad, c->n_pad_mfma);
+    const int    occ       = trace_occupancy(filter, lds_table, lds_bytes);
     const uint32_t max_grid = (uint32_t)c->num_cu * (uint32_t)occ;
     const uint64_t lanes    = (uint64_t)max_grid * kBlock;
 
@@ -226,18 +273,18 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     }
 
     TraceParams P{};
-    P.hot = c->hot; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
+    P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
     P.cols = cols; P.rows = rows; P.npix = npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = nchunks;
     P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = n_items;
     P.partials = c->partials; P.primary = want_primary ? c->primary : nullptr; P.work_counter = c->work_counter;
     P.stats = want_stats ? c->stats : nullptr;
 
     HIP_TRY(hipMemsetAsync(c->work_counter, 0, 256, c->stream));
-    if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, kStCount * sizeof(unsigned long long), c->stream));
+    if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 8) * sizeof(unsigned long long), c->stream));
     const uint32_t blocks_needed = (uint32_t)((n_items64 + kBlock - 1) / kBlock);
     const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(max_grid, blocks_needed));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
-    launch_trace(P, lds_table, grid, lds_bytes, c->stream);
+    HIP_TRY(launch_trace(P, filter, lds_table, validate, grid, lds_bytes, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     c->ev_trace = true;
@@ -317,8 +364,14 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         else HIP_TRY(hipMemcpy(primary_hit_host, c->primary, (size_t)cols * rows * spp_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     if (stats) {
-        unsigned long long h[kStCount];
+        unsigned long long h[kStCount + 8];
         HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
+        if (getenv("RTX_PRINT_PHASES")) {
+            static const char* names[8] = { "A fetch", "B camera", "C filter", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish" };
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; ++k) tot += h[kStCount + k];
+            for (int k = 0; k < 8 && tot; ++k) fprintf(stderr, "phase %-14s %6.2f %%\n", names[k], 100.0 * (double)h[kStCount + k] / (double)tot);
+        }
         memset(stats, 0, sizeof(*stats));
         if (max_depth == 0) {
             stats->samples = (uint64_t)cols * rows * spp_count;
@@ -326,6 +379,7 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         } else {
             stats->samples = h[kStSamples]; stats->rays = h[kStRays]; stats->sphere_tests = h[kStRays] * (uint64_t)c->n;
             stats->term_miss = h[kStMiss]; stats->term_absorb = h[kStAbsorb]; stats->term_depth = h[kStDepth]; stats->candidates = h[kStCandidates];
+            stats->filter_misses = h[kStFilterMiss];
         }
         stats->kernel_ms = ms;
     }

@@ -17,12 +17,21 @@ constexpr uint32_t kBlock      = 256;                  // threads per workgroup:
 constexpr uint32_t kWaveBatch  = 256;                  // work items a wave reserves per trip to the global counter
 constexpr uint32_t kListCap    = 16;                   // per-lane candidate list entries (LDS), flushed when full
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
-constexpr uint32_t kMaxLdsSpheres = 4096;              // hot table stays LDS-resident up to this many spheres
+// MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) per sphere and gamma * |o|^2 per ray, gamma = 2^-17.
+// It covers (5 kappa + 16) ulp * (|C|^2 + |o|^2) with kappa = 16, three times the worst accumulation error observed
+// for v_mfma_f32_16x16x32_bf16 (5.3 ulp of sum |terms|, tools/microbench/mfma_bf16_error.hip).
+constexpr float    kGammaRay   = 7.62939453125e-06f * 1.0625f;   // 2^-17 plus room for the rounding of |o|^2 itself
+constexpr double   kGammaSphere = 7.62939453125e-06;
+enum FilterKind { kFilterValu = 0, kFilterMfma = 1 };
+constexpr uint32_t kMaxLdsSpheres = 4096;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
+constexpr uint32_t kMaxLdsSpheresMfma = 1024;          // MFMA filter: 64 B/sphere
 
-enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStCount };
+enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStFilterMiss, kStCount };
 
 struct TraceParams {
-    const float4* hot;      // n_pad x (cx, cy, cz, -(r^2 (1+eps)))  -- the filter's view of a sphere
+    const float4* hot;      // n_pad x (cx, cy, cz, -(r^2 (1+eps)))  -- the VALU filter's view of a sphere
+    const float4* hot_mfma; // n_pad_mfma/16 tiles x 64 lanes x 16 B: bf16 A operands (cx, cy, cz, K'') of the MFMA filter
+    uint32_t      n_pad_mfma;
     const float4* exact;    // n x (cx, cy, cz, r)                   -- sphere.h:24-28 geometry, as uploaded
     const uint4*  mat;      // 2n: [2i] = (type, albedo r, g, b), [2i+1] = (blur, ior, 0, 0), float bits
     uint32_t      n, n_pad;
@@ -37,9 +46,9 @@ struct TraceParams {
     unsigned long long* stats; // kStCount counters
 };
 
-void launch_trace(const TraceParams& p, bool lds_table, uint32_t grid, size_t lds_bytes, hipStream_t stream);
-int  trace_occupancy(bool lds_table, size_t lds_bytes);
-size_t trace_lds_bytes(bool lds_table, uint32_t n_pad);
+hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, size_t lds_bytes, hipStream_t stream);
+int  trace_occupancy(int filter, bool lds_table, size_t lds_bytes);
+size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n_pad, uint32_t n_pad_mfma);
 void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream);
 void launch_fill(float* accum, uint32_t n_floats, float value, bool accumulate, hipStream_t stream);
 void launch_resolve(const float* accum, uint32_t* fb, uint32_t cols, uint32_t rows, uint32_t spp_total, uint32_t debug_tile, hipStream_t stream);

@@ -7,17 +7,28 @@
 //   Camera::getRay                     camera.h:75-86             -> new_sample()
 //   _color (iterative)                 raytracer.cpp:243-273      -> the bounce state kept in each lane
 //   _sceneHit + sphereHit              raytracer.cpp:285-304,
-//                                      sphere.cpp:68-102          -> conservative FMA filter over the LDS-staged SoA
-//                                                                   table + exact re-test of the few candidates
+//                                      sphere.cpp:68-102          -> conservative candidate filter over the LDS-staged
+//                                                                   sphere table (two forms, below) + exact re-test
+//                                                                   of the few candidates
 //   materialScatter and helpers        material.cu:17-138         -> shade()
 //   random / samplers                  utils.cu:65-94             -> Philox4x32-10 counter stream
 //
+// Two candidate filters share everything else (select with rtx_set_filter / RTX_FILTER):
+//   kFilterValu  : per lane, per sphere: oc = C - o, h = oc.d', q = |oc|^2 - r^2(1+eps), sign(q - h^2) -> 11 VALU ops
+//   kFilterMfma  : the same two bilinear forms h = C.d' - o.d' and c = K' - 2 o.C + |o|^2 evaluated for 16 spheres x 16
+//                  rays at a time on the matrix cores (v_mfma_f32_16x16x32_bf16); every f32 operand is split exactly
+//                  into three bf16 parts and the 8 significant partial products of each component fill the K = 32
+//                  dimension, so the products are exact and only the f32 accumulation rounds.  An absolute margin
+//                  proportional to |C|^2 + |o|^2 keeps it conservative ("filter margins").
+//
 // Numerics: everything that decides a result (camera ray, the exact sphere test, hit point, normal, scatter,
 // background, accumulation) is evaluated in the reference's operation order with contraction OFF, IEEE division and
-// square root, so a path is bit-identical to the CPU restatement in oracle/rt_oracle.c.  Only the candidate filter
-// uses FMAs and a reciprocal square root; it is conservative (never drops a sphere the exact test would accept), so
-// it cannot change a result -- only how many exact tests run.
+// square root, so a path is bit-identical to the CPU restatement of the reference.  Only the candidate filter uses
+// FMAs, MFMAs and a reciprocal square root; it is conservative (never drops a sphere the exact test would accept),
+// so it cannot change a result -- only how many exact tests run.
 #include "rtx_device.h"
+
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -48,8 +59,11 @@ __device__ __forceinline__ V3    normalized(V3 v)                               
 // Philox4x32-10 (Random123 constants).  key = seed, counter = (slot, sample, pixel, 0).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
 {
+#ifndef RTX_EXP_PHILOX_ROUNDS
+#define RTX_EXP_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < RTX_EXP_PHILOX_ROUNDS; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -80,29 +94,65 @@ __device__ __forceinline__ uint32_t rank_in(uint64_t mask)
 }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// Diagnostic build only (-DRTX_PHASE_TIMERS): per-phase wave cycles, s_memtime deltas summed into stats[kStCount + slot].
+#ifdef RTX_PHASE_TIMERS
+#define RTX_STAMP(slot) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph[slot] += now_ - ph_last; ph_last = now_; } while (0)
+#else
+#define RTX_STAMP(slot) do { } while (0)
+#endif
+
 enum LaneState : uint32_t { kNeedItem = 0, kNeedSample = 1, kTrace = 2, kDead = 3 };
 
+#ifndef RTX_MFMA_TILE_UNROLL
+#define RTX_MFMA_TILE_UNROLL 2
+#endif
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// Exact three-way split of an f32 into bf16 parts by truncation (x == p1 + p2 + p3), laid out for the ray (B) side
+// of the MFMA: elements (p1,p2,p1,p3,p2,p1,p3,p2) meet the sphere side's (s1,s1,s2,s1,s2,s3,s2,s3), i.e. every
+// partial product except s3*p3.
+__device__ __forceinline__ s8v split_ray_operand(float x)
+{
+    const uint32_t u1 = __float_as_uint(x) & 0xFFFF0000u;
+    const float    r1 = x - __uint_as_float(u1);
+    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float    r2 = r1 - __uint_as_float(u2);
+    const uint32_t u3 = __float_as_uint(r2) & 0xFFFF0000u;
+    const uint32_t h1 = u1 >> 16, h2 = u2 >> 16, h3 = u3 >> 16;
+    uint4 w;
+    w.x = h1 | u2;            // (p1, p2)
+    w.y = h1 | u3;            // (p1, p3)
+    w.z = h2 | u1;            // (p2, p1)
+    w.w = h3 | u2;            // (p3, p2)
+    return __builtin_bit_cast(s8v, w);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-template <bool LDS_TABLE>
+template <int FILTER, bool LDS_TABLE, bool VALIDATE>
 __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
 {
     extern __shared__ float4 smem[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
+    // candidate list entries: sphere indices fit 16 bits whenever the table is LDS-resident
+    typedef typename std::conditional<LDS_TABLE, uint16_t, uint32_t>::type list_t;
 
-    // (1) stage the filter's SoA table into LDS once per workgroup
-    const float4* hot;
-    uint32_t*     lists;
+    // (1) stage the filter's sphere table into LDS once per workgroup (16 B per sphere for the VALU filter,
+    //     64 B per sphere -- the bf16 A operands of 16-sphere tiles -- for the MFMA filter)
+    const float4* table = (FILTER == kFilterMfma) ? P.hot_mfma : P.hot;
+    const uint32_t table_f4 = (FILTER == kFilterMfma) ? P.n_pad_mfma * 4u : P.n_pad;
+    list_t* lists;
     if (LDS_TABLE) {
-        for (uint32_t i = threadIdx.x; i < P.n_pad; i += kBlock) smem[i] = P.hot[i];
+        for (uint32_t i = threadIdx.x; i < table_f4; i += kBlock) smem[i] = table[i];
         __syncthreads();
-        hot   = smem;
-        lists = reinterpret_cast<uint32_t*>(smem + P.n_pad);
+        table = smem;
+        lists = reinterpret_cast<list_t*>(smem + table_f4);
     } else {
-        hot   = P.hot;
-        lists = reinterpret_cast<uint32_t*>(smem);
+        lists = reinterpret_cast<list_t*>(smem);
     }
-    uint32_t* my_list = lists + wave * (kListCap * 64u) + lane;   // entry e of this lane: my_list[e * 64]
+    list_t* const my_list = lists + wave * (kListCap * 64u) + lane;    // entry e of this lane: my_list[e * 64]
+    float* const  xbuf    = reinterpret_cast<float*>(lists + wave * (kListCap * 64u));   // 2 KB ray exchange area (MFMA filter)
 
     // wave-level work reservation: [w_next, w_end) is owned, pf holds the next reservation (lane 0's value)
     uint32_t pf = 0;
@@ -116,12 +166,16 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
     V3       o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1), acc = mk(0, 0, 0);
     uint32_t n_cand = 0;
     // wave-level counters
-    uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0;
+    uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0, c_filter_miss = 0;
     uint64_t c_rays = 0;
 
     const V3 cam_o = ld3(P.cam.origin), cam_lc = ld3(P.cam.left_corner), cam_h = ld3(P.cam.horizontal), cam_v = ld3(P.cam.vertical);
     const V3 cam_uu = ld3(P.cam.u), cam_vv = ld3(P.cam.v);
 
+#ifdef RTX_PHASE_TIMERS
+    uint64_t ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint64_t ph_last = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         // ---- (A) lanes whose item is finished take the next one (persistent tile fetch) -------------------------
         uint64_t need = __ballot(st == kNeedItem);
@@ -154,6 +208,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             }
         }
 
+        RTX_STAMP(0);
         // ---- (B) camera rays for lanes starting a sample: raytracer.cpp:177-179 + camera.h:75-86 ------------------
         if (__ballot(st == kNeedSample)) {
             const bool go = (st == kNeedSample);
@@ -191,6 +246,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             }
         }
 
+        RTX_STAMP(1);
         const bool     tracing = (st == kTrace);
         const uint64_t tmask   = __ballot(tracing);
         if (!tmask) break;      // every lane is kDead: the queue is drained and all paths have ended
@@ -201,58 +257,154 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
         float       closest = 3.402823466e+38f;                           // FLT_MAX, raytracer.cpp:251
         uint32_t    best = kNoHit;
         {
-            const float rs = __builtin_amdgcn_rsqf(a) * (1.0f + kEps);
-            const float fx = d.x * rs, fy = d.y * rs, fz = d.z * rs;
-            uint32_t    cnt = 0;
+            uint32_t cnt = 0;
 
+            // sphere.cpp:72-99 for one candidate.  Candidates arrive in any order, so instead of relying on the
+            // ascending scan of raytracer.cpp:291-300 the tie rule is explicit: the hit distance of sphere i is its
+            // first root beyond t_min (the far root is only ever accepted when the near one is <= t_min, because
+            // far >= near), and among equal distances the lowest index wins, exactly as the strict '<' there decides.
+            auto exact_test = [&](uint32_t i) {
+                const float4 s = P.exact[i];
+                const V3    oc = sub(o, mk(s.x, s.y, s.z));
+                const float bq = dot(oc, d);
+                const float cq = dot(oc, oc) - (s.w * s.w);
+                const float disc = bq * bq - a * cq;
+                if (disc > 0) {
+                    const float sq = sqrtf(disc);
+                    float       t  = (-bq - sq) / a;
+                    if (!(t > 0.001f)) t = (-bq + sq) / a;
+                    if (t > 0.001f && (t < closest || (t == closest && i < best))) { closest = t; best = i; }
+                }
+            };
             auto process_lists = [&]() {
                 for (uint32_t e = 0; __ballot(e < cnt); ++e) {
-                    if (e < cnt) {
-                        const uint32_t i = my_list[e * 64u];
-                        const float4   s = P.exact[i];
-                        // sphere.cpp:72-99 in the reference's order
-                        const V3    oc = sub(o, mk(s.x, s.y, s.z));
-                        const float bq = dot(oc, d);
-                        const float cq = dot(oc, oc) - (s.w * s.w);
-                        const float disc = bq * bq - a * cq;
-                        if (disc > 0) {
-                            const float sq = sqrtf(disc);
-                            float       t  = (-bq - sq) / a;
-                            if (t < closest && t > 0.001f) { closest = t; best = i; }
-                            else {
-                                t = (-bq + sq) / a;
-                                if (t < closest && t > 0.001f) { closest = t; best = i; }
-                            }
-                        }
-                    }
+                    if (e < cnt) exact_test((uint32_t)my_list[e * 64u]);
                 }
                 n_cand += cnt;
                 cnt = 0;
             };
+            auto append = [&](uint32_t idx) {
+                my_list[cnt * 64u] = (list_t)idx;
+                cnt++;
+            };
 
-            for (uint32_t base = 0; base < P.n_pad; base += 32u) {
-                uint32_t m = 0;
+            if (FILTER == kFilterValu) {
+                const float rs = __builtin_amdgcn_rsqf(a) * (1.0f + kEps);
+                const float fx = d.x * rs, fy = d.y * rs, fz = d.z * rs;
+                for (uint32_t base = 0; base < P.n_pad; base += 32u) {
+                    uint32_t m = 0;
 #pragma unroll
-                for (uint32_t j = 0; j < 32u; ++j) {
-                    const float4 s   = hot[base + j];
-                    const float  ocx = s.x - o.x, ocy = s.y - o.y, ocz = s.z - o.z;
-                    const float  h   = __builtin_fmaf(ocz, fz, __builtin_fmaf(ocy, fy, ocx * fx));
-                    const float  q   = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, s.w)));
-                    const float  nd  = __builtin_fmaf(-h, h, q);     // < 0  <=>  inflated discriminant > 0
-                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(nd), 31u);
-                }
-                if (!tracing) m = 0;
-                while (__ballot(m != 0)) {
-                    if (m != 0) {
-                        const uint32_t j = (uint32_t)__clz((int)m);
-                        m &= ~(0x80000000u >> j);
-                        my_list[cnt * 64u] = base + j;
-                        cnt++;
+                    for (uint32_t j = 0; j < 32u; ++j) {
+                        const float4 s   = table[base + j];
+                        const float  ocx = s.x - o.x, ocy = s.y - o.y, ocz = s.z - o.z;
+                        const float  h   = __builtin_fmaf(ocz, fz, __builtin_fmaf(ocy, fy, ocx * fx));
+                        const float  q   = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, s.w)));
+                        const float  nd  = __builtin_fmaf(-h, h, q);     // < 0  <=>  inflated discriminant > 0
+                        m = __builtin_amdgcn_alignbit(m, __float_as_uint(nd), 31u);
                     }
-                    if (__ballot(cnt == kListCap)) process_lists();
+                    if (!tracing) m = 0;
+                    while (__ballot(m != 0)) {
+                        if (m != 0) {
+                            const uint32_t j = (uint32_t)__clz((int)m);
+                            m &= ~(0x80000000u >> j);
+                            append(base + j);
+                        }
+                        if (__ballot(cnt == kListCap)) process_lists();
+                    }
+                }
+            } else {
+                // ---- MFMA filter.  Lane (g = lane >> 4, q = lane & 15) of ray group rg works on ray 16 rg + q:
+                // it feeds component g of that ray into k-slots 8g..8g+7 and receives the results of spheres
+                // 4g..4g+3 of every 16-sphere tile.  Each ray's owner first publishes its filter quantities.
+                const float rs = __builtin_amdgcn_rsqf(a);
+                const float fx = d.x * rs, fy = d.y * rs, fz = d.z * rs;
+                const float od = __builtin_fmaf(o.z, fz, __builtin_fmaf(o.y, fy, o.x * fx));
+                const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+                xbuf[lane * 8u + 0u] = fx;  xbuf[lane * 8u + 1u] = fy;  xbuf[lane * 8u + 2u] = fz;
+                xbuf[lane * 8u + 3u] = -2.0f * o.x; xbuf[lane * 8u + 4u] = -2.0f * o.y; xbuf[lane * 8u + 5u] = -2.0f * o.z;
+                xbuf[lane * 8u + 6u] = -od;
+                xbuf[lane * 8u + 7u] = oo - kGammaRay * oo;                // |o|^2 minus the per-ray share of the margin
+                const uint32_t g = lane >> 4, q = lane & 15u;
+                s8v   bh[4], bc[4];
+                f4v   ch[4];
+                float ooa[4];
+#pragma unroll
+                for (uint32_t rg = 0; rg < 4u; ++rg) {
+                    const uint32_t src = (rg * 16u + q) * 8u;
+                    const float vh = (g < 3u) ? xbuf[src + g] : 0.0f;       // h = C.d' (+ the -o.d' accumulator below)
+                    const float vc = (g < 3u) ? xbuf[src + 3u + g] : 1.0f;  // c = -2 o.C + K'' * 1
+                    const float mo = xbuf[src + 6u];
+                    ooa[rg] = xbuf[src + 7u];
+                    bh[rg]  = split_ray_operand(vh);
+                    bc[rg]  = split_ray_operand(vc);
+                    ch[rg]  = f4v{ mo, mo, mo, mo };
+                }
+                const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t: tabA[t * 64]
+
+                for (uint32_t base = 0; base < P.n_pad_mfma; base += 128u) {
+                    uint32_t mk[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll RTX_MFMA_TILE_UNROLL
+                    for (uint32_t tt = 0; tt < 8u; ++tt) {
+                        const s8v A = __builtin_bit_cast(s8v, tabA[((base >> 4) + tt) * 64u]);
+#pragma unroll
+                        for (uint32_t rg = 0; rg < 4u; ++rg) {
+                            const f4v h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rg], ch[rg], 0, 0, 0);
+                            f4v w;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(-h[j], h[j], ooa[rg]);
+                            w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rg], w, 0, 0, 0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) mk[rg] = __builtin_amdgcn_alignbit(mk[rg], __float_as_uint(w[j]), 31u);
+                        }
+                    }
+                    // 4 x 4 transpose among lanes q, q+16, q+32, q+48: the owner of ray 16 g + q collects, from lane
+                    // group gs = (g + s) & 3, the word that group built for ray group g.
+#pragma unroll
+                    for (uint32_t s = 0; s < 4u; ++s) {
+                        const uint32_t sel  = (g - s) & 3u;
+                        uint32_t       word = sel == 0u ? mk[0] : (sel == 1u ? mk[1] : (sel == 2u ? mk[2] : mk[3]));
+                        const uint32_t gs   = (g + s) & 3u;
+                        if (s != 0u) word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((gs * 16u + q) * 4u), (int)word);
+                        if (!tracing) word = 0;
+                        // bit 31 - (4 tt + j) of the word from group gs  <->  sphere base + 16 tt + 4 gs + j
+                        while (__ballot(word != 0)) {
+                            if (word != 0) {
+                                const uint32_t pbit = (uint32_t)__clz((int)word);
+                                word &= ~(0x80000000u >> pbit);
+                                append(base + ((pbit >> 2) << 4) + (gs << 2) + (pbit & 3u));
+                            }
+                            if (__ballot(cnt == kListCap)) process_lists();
+                        }
+                    }
                 }
             }
+            RTX_STAMP(2);
             process_lists();
+            RTX_STAMP(3);
+
+            if (VALIDATE) {
+                // debug build of the kernel: the reference's full ascending scan next to the filtered result
+                float    c2 = 3.402823466e+38f;
+                uint32_t b2 = kNoHit;
+                for (uint32_t i = 0; i < P.n; ++i) {
+                    const float4 s = P.exact[i];
+                    const V3    oc = sub(o, mk(s.x, s.y, s.z));
+                    const float bq = dot(oc, d);
+                    const float cq = dot(oc, oc) - (s.w * s.w);
+                    const float disc = bq * bq - a * cq;
+                    if (disc > 0) {
+                        const float sq = sqrtf(disc);
+                        float       t  = (-bq - sq) / a;
+                        if (t < c2 && t > 0.001f) { c2 = t; b2 = i; }
+                        else {
+                            t = (-bq + sq) / a;
+                            if (t < c2 && t > 0.001f) { c2 = t; b2 = i; }
+                        }
+                    }
+                }
+                const uint64_t bad = __ballot(tracing && (b2 != best || (b2 != kNoHit && c2 != closest)));
+                c_filter_miss += (uint32_t)__popcll(bad);
+            }
         }
 
         // ---- (D) shade: raytracer.cpp:250-270 + material.cu ------------------------------------------------------
@@ -275,6 +427,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             hn     = divs(sub(hp, mk(s.x, s.y, s.z)), s.w);              // sphere.cpp:84
         }
 
+        RTX_STAMP(4);
         // randomInUnitSphere (utils.cu:74-83) for the diffuse and metal lanes: try t from block t of event bounce+1
         V3 rnd = mk(0, 0, 0);
         {
@@ -291,6 +444,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             }
         }
 
+        RTX_STAMP(5);
         if (hit) {
             V3   att = albedo, nd_ = d;
             bool ok  = true;
@@ -362,6 +516,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
         c_absorb += (uint32_t)__popcll(__ballot(absorbed));
         c_depth  += (uint32_t)__popcll(__ballot(depth_end));
 
+        RTX_STAMP(6);
         // ---- (E) a finished path is added to its item; a finished item is written out ----------------------------
         if (ended) {
             acc = add(acc, thr);                                          // color += _color(...), raytracer.cpp:184
@@ -374,6 +529,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             }
         }
         c_samples += (uint32_t)__popcll(__ballot(ended));
+        RTX_STAMP(7);
     }
 
     // wave totals -> global statistics
@@ -387,6 +543,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             atomicAdd(&P.stats[kStAbsorb], (unsigned long long)c_absorb);
             atomicAdd(&P.stats[kStDepth], (unsigned long long)c_depth);
             atomicAdd(&P.stats[kStCandidates], (unsigned long long)v);
+            atomicAdd(&P.stats[kStFilterMiss], (unsigned long long)c_filter_miss);
+#ifdef RTX_PHASE_TIMERS
+            for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[kStCount + k], (unsigned long long)ph[k]);
+#endif
         }
     }
 }
@@ -434,24 +594,38 @@ __global__ void __launch_bounds__(256) resolve_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-size_t trace_lds_bytes(bool lds_table, uint32_t n_pad)
+template <int FILTER, bool LDS, bool VAL> static const void* kernel_ptr() { return (const void*)trace_kernel<FILTER, LDS, VAL>; }
+
+static const void* select_kernel(int filter, bool lds_table, bool validate)
 {
-    return (lds_table ? (size_t)n_pad * sizeof(float4) : 0) + (size_t)(kBlock / 64) * kListCap * 64 * sizeof(uint32_t);
+    if (filter == kFilterMfma) {
+        if (lds_table) return validate ? kernel_ptr<kFilterMfma, true, true>() : kernel_ptr<kFilterMfma, true, false>();
+        return validate ? kernel_ptr<kFilterMfma, false, true>() : kernel_ptr<kFilterMfma, false, false>();
+    }
+    if (lds_table) return validate ? kernel_ptr<kFilterValu, true, true>() : kernel_ptr<kFilterValu, true, false>();
+    return validate ? kernel_ptr<kFilterValu, false, true>() : kernel_ptr<kFilterValu, false, false>();
 }
 
-int trace_occupancy(bool lds_table, size_t lds_bytes)
+size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n_pad, uint32_t n_pad_mfma)
+{
+    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)n_pad_mfma * 64 : (size_t)n_pad * 16) : 0;
+    const size_t entry = lds_table ? sizeof(uint16_t) : sizeof(uint32_t);
+    return table + (size_t)(kBlock / 64) * kListCap * 64 * entry;
+}
+
+int trace_occupancy(int filter, bool lds_table, size_t lds_bytes)
 {
     int blocks = 0;
-    hipError_t e = lds_table ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<true>, kBlock, lds_bytes)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<false>, kBlock, lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, select_kernel(filter, lds_table, false), kBlock, lds_bytes);
     if (e != hipSuccess || blocks < 1) blocks = 1;
     return blocks;
 }
 
-void launch_trace(const TraceParams& p, bool lds_table, uint32_t grid, size_t lds_bytes, hipStream_t stream)
+hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, size_t lds_bytes, hipStream_t stream)
 {
-    if (lds_table) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, p);
-    else           hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(kBlock), lds_bytes, stream, p);
+    TraceParams copy = p;
+    void* args[] = { &copy };
+    return hipLaunchKernel(select_kernel(filter, lds_table, validate), dim3(grid), dim3(kBlock), args, lds_bytes, stream);
 }
 
 void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream)
