@@ -84,7 +84,7 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
     if (e == hipSuccess) e = hipMalloc(&c->work_counter, 256);
-    if (e == hipSuccess) e = hipMalloc(&c->stats, (kStCount + 8) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->stats, (kStCount + 12) * sizeof(unsigned long long));
     if (e != hipSuccess) { rtx_destroy(c); return fail(RTX_ERR_DEVICE, "rtx_create: %s", hipGetErrorString(e)); }
     *out_ctx = c;
     return RTX_OK;
@@ -135,7 +135,7 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     // MFMA filter: per 16-sphere tile, lane (g = lane >> 4, r = lane & 15) holds component g of sphere 16 t + r as the
     // eight bf16 (s1,s1,s2,s1,s2,s3,s2,s3) of its exact three-way split; component 3 is K'' = |C|^2 - r^2 - margin.
     const uint32_t n_pad_mfma = (n + 127u) & ~127u;
-    std::vector<uint4> tabA((size_t)std::max<uint32_t>(n_pad_mfma, 128u) * 4u);
+    std::vector<uint4> tabA(((size_t)n_pad_mfma + 16u) * 4u);      // + one spare tile: the kernel prefetches one tile ahead
     auto split3 = [](float x, uint32_t h[3]) {
         float rem = x;
         for (int k = 0; k < 3; ++k) {
@@ -145,7 +145,7 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
             rem -= part;                      // exact: part is the truncation of rem
         }
     };
-    for (uint32_t i = 0; i < n_pad_mfma; ++i) {
+    for (uint32_t i = 0; i < n_pad_mfma + 16u; ++i) {
         float comp[4] = { 0.0f, 0.0f, 0.0f, 1.0e30f };           // padding: c = 1e30 + ..., never negative
         if (i < n) {
             const double C2 = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
@@ -240,17 +240,19 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         launch_fill(c->accum, npix * 3, (float)spp_count, accumulate, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_last, c->stream));
-        if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 8) * sizeof(unsigned long long), c->stream));
+        if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
         return RTX_OK;
     }
 
     const bool   validate  = (flags & RTX_FLAG_VALIDATE_FILTER) != 0;
     const int    filter    = c->filter;
     const bool   lds_table = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
-    const size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n_pad, c->n_pad_mfma);
-    const int    occ       = trace_occupancy(filter, lds_table, lds_bytes);
+    uint32_t block = 256u;
+    if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) block = (uint32_t)v; }
+    const size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, block);
+    const int    occ       = trace_occupancy(filter, lds_table, lds_bytes, block);
     const uint32_t max_grid = (uint32_t)c->num_cu * (uint32_t)occ;
-    const uint64_t lanes    = (uint64_t)max_grid * kBlock;
+    const uint64_t lanes    = (uint64_t)max_grid * block;
 
     // sample chunking: enough work items for dynamic balance and a short tail, few enough to keep the partial
     // buffer small.  One chunk reproduces the reference's summation order exactly.
@@ -280,11 +282,11 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     P.stats = want_stats ? c->stats : nullptr;
 
     HIP_TRY(hipMemsetAsync(c->work_counter, 0, 256, c->stream));
-    if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 8) * sizeof(unsigned long long), c->stream));
-    const uint32_t blocks_needed = (uint32_t)((n_items64 + kBlock - 1) / kBlock);
+    if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
+    const uint32_t blocks_needed = (uint32_t)((n_items64 + block - 1) / block);
     const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(max_grid, blocks_needed));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
-    HIP_TRY(launch_trace(P, filter, lds_table, validate, grid, lds_bytes, c->stream));
+    HIP_TRY(launch_trace(P, filter, lds_table, validate, grid, block, lds_bytes, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     c->ev_trace = true;
@@ -364,13 +366,13 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         else HIP_TRY(hipMemcpy(primary_hit_host, c->primary, (size_t)cols * rows * spp_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     if (stats) {
-        unsigned long long h[kStCount + 8];
+        unsigned long long h[kStCount + 12];
         HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
         if (getenv("RTX_PRINT_PHASES")) {
-            static const char* names[8] = { "A fetch", "B camera", "C filter", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish" };
+            static const char* names[12] = { "A fetch", "B camera", "C filter tiles", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish", "C filter setup", "C extract", "-", "-" };
             unsigned long long tot = 0;
-            for (int k = 0; k < 8; ++k) tot += h[kStCount + k];
-            for (int k = 0; k < 8 && tot; ++k) fprintf(stderr, "phase %-14s %6.2f %%\n", names[k], 100.0 * (double)h[kStCount + k] / (double)tot);
+            for (int k = 0; k < 12; ++k) tot += h[kStCount + k];
+            for (int k = 0; k < 10 && tot; ++k) fprintf(stderr, "phase %-14s %6.2f %%\n", names[k], 100.0 * (double)h[kStCount + k] / (double)tot);
         }
         memset(stats, 0, sizeof(*stats));
         if (max_depth == 0) {

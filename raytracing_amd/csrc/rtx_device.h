@@ -13,7 +13,7 @@ namespace rtx
 // The filter works on the inflated quantities r^2 (1 + kEps) and h^2 (1 + kEps)^2; kEps = 2^-17 = 128 ulp covers
 // the <= 34 ulp that the reference's own rounding of b*b - a*c can move the sign of the discriminant.
 constexpr float    kEps        = 7.62939453125e-06f;  // 2^-17
-constexpr uint32_t kBlock      = 256;                  // threads per workgroup: 4 waves, one per SIMD
+constexpr uint32_t kMaxBlock   = 512;                  // threads per workgroup (launch bound); the block size is chosen per launch
 constexpr uint32_t kWaveBatch  = 256;                  // work items a wave reserves per trip to the global counter
 constexpr uint32_t kListCap    = 16;                   // per-lane candidate list entries (LDS), flushed when full
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
@@ -23,7 +23,7 @@ constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
 constexpr float    kGammaRay   = 7.62939453125e-06f * 1.0625f;   // 2^-17 plus room for the rounding of |o|^2 itself
 constexpr double   kGammaSphere = 7.62939453125e-06;
 enum FilterKind { kFilterValu = 0, kFilterMfma = 1 };
-constexpr uint32_t kMaxLdsSpheres = 4096;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
+constexpr uint32_t kMaxLdsSpheres = 2048;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
 constexpr uint32_t kMaxLdsSpheresMfma = 1024;          // MFMA filter: 64 B/sphere
 
 enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStFilterMiss, kStCount };
@@ -46,9 +46,9 @@ struct TraceParams {
     unsigned long long* stats; // kStCount counters
 };
 
-hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, size_t lds_bytes, hipStream_t stream);
-int  trace_occupancy(int filter, bool lds_table, size_t lds_bytes);
-size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n_pad, uint32_t n_pad_mfma);
+hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, uint32_t block, size_t lds_bytes, hipStream_t stream);
+int  trace_occupancy(int filter, bool lds_table, size_t lds_bytes, uint32_t block);
+size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block);
 void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream);
 void launch_fill(float* accum, uint32_t n_floats, float value, bool accumulate, hipStream_t stream);
 void launch_resolve(const float* accum, uint32_t* fb, uint32_t cols, uint32_t rows, uint32_t spp_total, uint32_t debug_tile, hipStream_t stream);

@@ -130,7 +130,7 @@ __device__ __forceinline__ s8v split_ray_operand(float x)
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int FILTER, bool LDS_TABLE, bool VALIDATE>
-__global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
+__global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
 {
     extern __shared__ float4 smem[];
     const uint32_t lane = lane_id();
@@ -143,11 +143,15 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
     const float4* table = (FILTER == kFilterMfma) ? P.hot_mfma : P.hot;
     const uint32_t table_f4 = (FILTER == kFilterMfma) ? P.n_pad_mfma * 4u : P.n_pad;
     list_t* lists;
+    const float4* exact = P.exact;
     if (LDS_TABLE) {
-        for (uint32_t i = threadIdx.x; i < table_f4; i += kBlock) smem[i] = table[i];
+        // table, then the exact (cx, cy, cz, r) records the candidate re-test reads, then the per-wave lists
+        for (uint32_t i = threadIdx.x; i < table_f4; i += blockDim.x) smem[i] = table[i];
+        for (uint32_t i = threadIdx.x; i < P.n; i += blockDim.x) smem[table_f4 + i] = P.exact[i];
         __syncthreads();
         table = smem;
-        lists = reinterpret_cast<list_t*>(smem + table_f4);
+        exact = smem + table_f4;
+        lists = reinterpret_cast<list_t*>(smem + table_f4 + ((P.n + 3u) & ~3u));
     } else {
         lists = reinterpret_cast<list_t*>(smem);
     }
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
     const V3 cam_uu = ld3(P.cam.u), cam_vv = ld3(P.cam.v);
 
 #ifdef RTX_PHASE_TIMERS
-    uint64_t ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint64_t ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     uint64_t ph_last = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
@@ -264,7 +268,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             // first root beyond t_min (the far root is only ever accepted when the near one is <= t_min, because
             // far >= near), and among equal distances the lowest index wins, exactly as the strict '<' there decides.
             auto exact_test = [&](uint32_t i) {
-                const float4 s = P.exact[i];
+                const float4 s = exact[i];
                 const V3    oc = sub(o, mk(s.x, s.y, s.z));
                 const float bq = dot(oc, d);
                 const float cq = dot(oc, oc) - (s.w * s.w);
@@ -341,41 +345,59 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
                 }
                 const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t: tabA[t * 64]
 
+                RTX_STAMP(8);
+                s8v A_next = __builtin_bit_cast(s8v, tabA[0]);
                 for (uint32_t base = 0; base < P.n_pad_mfma; base += 128u) {
                     uint32_t mk[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll RTX_MFMA_TILE_UNROLL
                     for (uint32_t tt = 0; tt < 8u; ++tt) {
-                        const s8v A = __builtin_bit_cast(s8v, tabA[((base >> 4) + tt) * 64u]);
+                        const s8v A = A_next;
+                        A_next = __builtin_bit_cast(s8v, tabA[((base >> 4) + tt + 1u) * 64u]);   // the table ends with a spare tile
+                        f4v h[4], w[4];
+#pragma unroll
+                        for (uint32_t rg = 0; rg < 4u; ++rg) h[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rg], ch[rg], 0, 0, 0);
 #pragma unroll
                         for (uint32_t rg = 0; rg < 4u; ++rg) {
-                            const f4v h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rg], ch[rg], 0, 0, 0);
-                            f4v w;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(-h[j], h[j], ooa[rg]);
-                            w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rg], w, 0, 0, 0);
+                            for (int j = 0; j < 4; ++j) w[rg][j] = __builtin_fmaf(-h[rg][j], h[rg][j], ooa[rg]);
+                        }
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) mk[rg] = __builtin_amdgcn_alignbit(mk[rg], __float_as_uint(w[j]), 31u);
+                        for (uint32_t rg = 0; rg < 4u; ++rg) w[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rg], w[rg], 0, 0, 0);
+#pragma unroll
+                        for (uint32_t rg = 0; rg < 4u; ++rg) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) mk[rg] = __builtin_amdgcn_alignbit(mk[rg], __float_as_uint(w[rg][j]), 31u);
                         }
                     }
+                    RTX_STAMP(2);
                     // 4 x 4 transpose among lanes q, q+16, q+32, q+48: the owner of ray 16 g + q collects, from lane
                     // group gs = (g + s) & 3, the word that group built for ray group g.
+                    uint32_t word[4];
 #pragma unroll
                     for (uint32_t s = 0; s < 4u; ++s) {
-                        const uint32_t sel  = (g - s) & 3u;
-                        uint32_t       word = sel == 0u ? mk[0] : (sel == 1u ? mk[1] : (sel == 2u ? mk[2] : mk[3]));
-                        const uint32_t gs   = (g + s) & 3u;
-                        if (s != 0u) word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((gs * 16u + q) * 4u), (int)word);
-                        if (!tracing) word = 0;
-                        // bit 31 - (4 tt + j) of the word from group gs  <->  sphere base + 16 tt + 4 gs + j
-                        while (__ballot(word != 0)) {
-                            if (word != 0) {
-                                const uint32_t pbit = (uint32_t)__clz((int)word);
-                                word &= ~(0x80000000u >> pbit);
-                                append(base + ((pbit >> 2) << 4) + (gs << 2) + (pbit & 3u));
-                            }
-                            if (__ballot(cnt == kListCap)) process_lists();
+                        const uint32_t sel = (g - s) & 3u;
+                        word[s] = sel == 0u ? mk[0] : (sel == 1u ? mk[1] : (sel == 2u ? mk[2] : mk[3]));
+                    }
+#pragma unroll
+                    for (uint32_t s = 1; s < 4u; ++s)
+                        word[s] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((((g + s) & 3u) << 4) + q) << 2), (int)word[s]);
+                    if (!tracing) { word[0] = 0; word[1] = 0; word[2] = 0; word[3] = 0; }
+                    // bit 31 - (4 tt + j) of the word from group gs  <->  sphere base + 16 tt + 4 gs + j.  Each round takes
+                    // one candidate out of each of the four words, branch-free (an empty word stores a dummy entry
+                    // that the unchanged count leaves dead), so a round costs one ballot whatever the lanes hold.
+                    while (__ballot((word[0] | word[1] | word[2] | word[3]) != 0)) {
+                        if (__ballot(cnt + 4u > kListCap)) process_lists();
+#pragma unroll
+                        for (uint32_t s = 0; s < 4u; ++s) {
+                            const uint32_t wv   = word[s];
+                            const uint32_t pbit = 31u - (uint32_t)__builtin_ctz(wv | 0x80000000u) ;   // position from the top; any value when wv == 0
+                            const uint32_t gs   = (g + s) & 3u;
+                            my_list[cnt * 64u] = (list_t)(base + ((pbit >> 2) << 4) + (gs << 2) + (pbit & 3u));
+                            cnt += (wv != 0u) ? 1u : 0u;
+                            word[s] = wv & (wv - 1u);
                         }
                     }
+                    RTX_STAMP(9);
                 }
             }
             RTX_STAMP(2);
@@ -417,7 +439,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
         V3         albedo = mk(0, 0, 0), hp = mk(0, 0, 0), hn = mk(0, 0, 0);
         float      blur = 0, ior = 1;
         if (hit) {
-            const float4 s  = P.exact[best];
+            const float4 s  = exact[best];
             const uint4  m0 = P.mat[2u * best], m1 = P.mat[2u * best + 1u];
             mtype  = m0.x;
             albedo = mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w));
@@ -545,7 +567,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P)
             atomicAdd(&P.stats[kStCandidates], (unsigned long long)v);
             atomicAdd(&P.stats[kStFilterMiss], (unsigned long long)c_filter_miss);
 #ifdef RTX_PHASE_TIMERS
-            for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[kStCount + k], (unsigned long long)ph[k]);
+            for (int k = 0; k < 12; ++k) atomicAdd(&P.stats[kStCount + k], (unsigned long long)ph[k]);
 #endif
         }
     }
@@ -606,26 +628,33 @@ static const void* select_kernel(int filter, bool lds_table, bool validate)
     return validate ? kernel_ptr<kFilterValu, false, true>() : kernel_ptr<kFilterValu, false, false>();
 }
 
-size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n_pad, uint32_t n_pad_mfma)
+size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block)
 {
-    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)n_pad_mfma * 64 : (size_t)n_pad * 16) : 0;
+    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 16) * 64 : (size_t)n_pad * 16) : 0;
     const size_t entry = lds_table ? sizeof(uint16_t) : sizeof(uint32_t);
-    return table + (size_t)(kBlock / 64) * kListCap * 64 * entry;
+    const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
+    return table + exact + (size_t)(block / 64) * kListCap * 64 * entry;
 }
 
-int trace_occupancy(int filter, bool lds_table, size_t lds_bytes)
+int trace_occupancy(int filter, bool lds_table, size_t lds_bytes, uint32_t block)
 {
     int blocks = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, select_kernel(filter, lds_table, false), kBlock, lds_bytes);
+    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute(select_kernel(filter, lds_table, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, select_kernel(filter, lds_table, false), (int)block, lds_bytes);
     if (e != hipSuccess || blocks < 1) blocks = 1;
     return blocks;
 }
 
-hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, size_t lds_bytes, hipStream_t stream)
+hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, uint32_t block, size_t lds_bytes, hipStream_t stream)
 {
     TraceParams copy = p;
     void* args[] = { &copy };
-    return hipLaunchKernel(select_kernel(filter, lds_table, validate), dim3(grid), dim3(kBlock), args, lds_bytes, stream);
+    const void* fn = select_kernel(filter, lds_table, validate);
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipLaunchKernel(fn, dim3(grid), dim3(block), args, lds_bytes, stream);
 }
 
 void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream)
