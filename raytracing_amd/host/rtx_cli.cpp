@@ -1,0 +1,95 @@
+// rtx_cli.cpp -- the command line of the reference (RayTracing.cpp:42-180) with the GPU mode added.
+// Keeps -a -b -d -f -m -r -t; adds -g (HIP backend, the default and only renderer here), -w / -h (image size, the
+// reference's COLS / ROWS are compile-time, RayTracing.cpp:23-24), -s (seed), -n book1|glass|scaled (scene variant),
+// -G device.  -c (CUDA) and -i (ISPC) name back ends this build does not contain and are refused.
+#include "scene_types.h"
+#include "render_scene_hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace pk;
+
+class ArgsParser {   // same behaviour as argsparser.h:10-37
+public:
+    ArgsParser(int argc, char** argv) { for (int i = 1; i < argc; ++i) tokens.push_back(argv[i]); }
+    const std::string& getCmdOption(const std::string& option) const
+    {
+        static const std::string empty;
+        auto it = std::find(tokens.begin(), tokens.end(), option);
+        if (it != tokens.end() && ++it != tokens.end()) return *it;
+        return empty;
+    }
+    bool cmdOptionExists(const std::string& option) const { return std::find(tokens.begin(), tokens.end(), option) != tokens.end(); }
+private:
+    std::vector<std::string> tokens;
+};
+
+static Scene* randomScene(uint64_t seed, const std::string& variant)   // RayTracing.cpp:182-213, seeded
+{
+    int grid_half = 11; float p_diffuse = 0.8f, p_metal = 0.95f;
+    if (variant == "glass") p_diffuse = 0.1f;
+    if (variant == "scaled") grid_half = 71;
+    const uint32_t cap = rtx_scene_capacity(grid_half);
+    std::vector<float> f[9]; for (auto& v : f) v.resize(cap);
+    std::vector<uint32_t> type(cap);
+    uint32_t n = 0;
+    rtx_random_scene(seed, grid_half, p_diffuse, p_metal, &n, f[0].data(), f[1].data(), f[2].data(), f[3].data(), type.data(), f[4].data(), f[5].data(), f[6].data(), f[7].data(), f[8].data());
+    Scene* scene = new Scene();
+    for (uint32_t i = 0; i < n; ++i)
+        scene->objects.push_back(new Sphere(vector3(f[0][i], f[1][i], f[2][i]), f[3][i], new material_t((material_type_t)type[i], vector3(f[4][i], f[5][i], f[6][i]), f[7][i], f[8][i])));
+    return scene;
+}
+
+int main(int argc, char** argv)
+{
+    ArgsParser args(argc, argv);
+    if (args.cmdOptionExists("-c") || args.cmdOptionExists("-i")) { printf("Error: this build contains the HIP backend only (-g); -c and -i are not available.\n"); return -1; }
+    int aaSamples = 24;                                            // NUM_AA_SAMPLES, RayTracing.cpp:31
+    if (args.cmdOptionExists("-a")) aaSamples = std::stoi(args.getCmdOption("-a"));
+    int blockSize = 64;
+    if (args.cmdOptionExists("-b")) blockSize = std::stoi(args.getCmdOption("-b"));
+    bool debug = args.cmdOptionExists("-d");
+    std::string filename = "foo.ppm";
+    if (args.cmdOptionExists("-f")) filename = args.getCmdOption("-f");
+    int maxBounce = 5;                                             // MAX_RAY_DEPTH, RayTracing.cpp:34
+    if (args.cmdOptionExists("-m")) maxBounce = std::stoi(args.getCmdOption("-m"));
+    bool recursive = args.cmdOptionExists("-r");
+    int numThreads = (int)std::thread::hardware_concurrency() - 1;
+    if (args.cmdOptionExists("-t")) numThreads = std::stoi(args.getCmdOption("-t"));
+    unsigned cols = 2000, rows = 1000;                             // COLS, ROWS, RayTracing.cpp:23-24
+    if (args.cmdOptionExists("-w")) cols = (unsigned)std::stoi(args.getCmdOption("-w"));
+    if (args.cmdOptionExists("-h")) rows = (unsigned)std::stoi(args.getCmdOption("-h"));
+    uint64_t seed = 1;
+    if (args.cmdOptionExists("-s")) seed = std::stoull(args.getCmdOption("-s"));
+    std::string variant = "book1";
+    if (args.cmdOptionExists("-n")) variant = args.getCmdOption("-n");
+    int device = 0;
+    if (args.cmdOptionExists("-G")) device = std::stoi(args.getCmdOption("-G"));
+
+    Scene* scene = randomScene(seed, variant);
+    Camera camera(20, float(cols) / float(rows), 0.1f, 10.0f, vector3(13, 2, 3), vector3(0, 1, 0), vector3(0, 0, 0));   // RayTracing.cpp:107-117
+
+    std::vector<uint32_t> frameBuffer((size_t)rows * cols, 0xCCCCCCCCu);
+    FILE* probe = fopen(filename.c_str(), "w");
+    if (!probe) { printf("Error: failed to open [%s] for writing.\n", filename.c_str()); delete scene; return -1; }
+    fclose(probe);
+
+    rtx_stats st;
+    auto t0 = std::chrono::steady_clock::now();
+    int  rc = renderSceneHIP(*scene, camera, rows, cols, frameBuffer.data(), aaSamples, maxBounce, numThreads, blockSize, debug, recursive, seed, device, &st);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != 0) { delete scene; return -1; }
+    printf("renderSceneHIP: %f s (%zu spheres, %u x %u, %d spp, depth %d)\n", sec, scene->objects.size(), cols, rows, aaSamples, maxBounce);
+    printf("{\"msamples_per_s\": %.3f, \"mrays_per_s\": %.3f, \"kernel_ms\": %.3f, \"rays\": %llu, \"samples\": %llu}\n",
+           st.samples / (st.kernel_ms * 1e3), st.rays / (st.kernel_ms * 1e3), st.kernel_ms, (unsigned long long)st.rays, (unsigned long long)st.samples);
+    rc = rtx_write_ppm(filename.c_str(), cols, rows, frameBuffer.data());
+    delete scene;
+    return rc == 0 ? 0 : -1;
+}

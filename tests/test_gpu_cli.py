@@ -1,0 +1,31 @@
+"""The standalone C++ host (rtx_cli: the reference's flags + the HIP mode) end to end: PPM on disk equals the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_writes_reference_format_ppm(tmp_path, oracle, golden_scenes):
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    if not os.path.exists(cli):
+        pytest.fail("raytracing_amd/rtx_cli is not built (make -C raytracing_amd/csrc cli)")
+    out = tmp_path / "img.ppm"
+    cols, rows, spp, depth = 60, 40, 3, 7
+    r = subprocess.run([cli, "-w", str(cols), "-h", str(rows), "-a", str(spp), "-m", str(depth), "-s", "1", "-f", str(out), "-t", "4", "-b", "16"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().split("\n")
+    assert lines[:3] == ["P3", "%d %d" % (cols, rows), "255"]
+    px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + cols * rows]], dtype=np.uint32)
+    accum, _, _ = oracle.render(golden_scenes["book1"], oracle.book_camera(cols, rows), rows, cols, 0, spp, depth, 1)
+    fb = oracle.resolve(accum, rows, cols, spp)
+    want = np.stack([(fb >> 24) & 0xFF, (fb >> 16) & 0xFF, (fb >> 8) & 0xFF], axis=1)
+    assert (px == want).all()
+    # -c / -i name back ends this build does not have
+    r = subprocess.run([cli, "-c"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "not available" in r.stdout
