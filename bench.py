@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--chunk-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and all-reduce even with one rank (rehearsal of the N > 1 path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,7 +71,8 @@ def main():
     from raytracing_amd.multi_gpu import TorchAccum
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -84,7 +86,7 @@ def main():
 
     def step():
         ctx.render_async(cols, rows, spp_begin, spp, DEPTH, SEED, 0, args.chunk_spp)
-        if world > 1:
+        if use_dist:
             accum.allreduce()
         if rank == 0:
             ctx.resolve(spp * world)
@@ -92,7 +94,7 @@ def main():
             ctx.sync()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()
@@ -109,7 +111,7 @@ def main():
         trace_ms.append(ctx.last_trace_ms())     # HIP events around the trace kernel, on the stream it ran on
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -142,7 +144,7 @@ def main():
         print(json.dumps(out))
     accum.release()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

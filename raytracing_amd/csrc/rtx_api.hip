@@ -159,7 +159,12 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
         for (uint32_t g = 0; g < 4u; ++g) {
             uint32_t h[3];
             split3(comp[g], h);
-            tabA[(size_t)t * 64u + g * 16u + r] = make_uint4(h[0] | (h[0] << 16), h[1] | (h[0] << 16), h[1] | (h[2] << 16), h[1] | (h[2] << 16));
+            // groups 0..2 (cx, cy, cz): (s1,s1, s2,s1, s2,s3, s2,s3); group 3 (K''): (s1,ONE, s2,ONE, ONE,s3, 0,0) -- the
+            // ONEs carry the ray's -o.d' into the h form, where K'' meets zeros, and meet zeros in the c form
+            const uint32_t ONE = 0x3F80u;
+            tabA[(size_t)t * 64u + g * 16u + r] = (g < 3u)
+                ? make_uint4(h[0] | (h[0] << 16), h[1] | (h[0] << 16), h[1] | (h[2] << 16), h[1] | (h[2] << 16))
+                : make_uint4(h[0] | (ONE << 16), h[1] | (ONE << 16), ONE | (h[2] << 16), 0u);
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -249,7 +254,8 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     const bool   lds_table = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
     uint32_t block = 256u;
     if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) block = (uint32_t)v; }
-    const size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, block);
+    size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, block);
+    if (const char* pad = getenv("RTX_LDS_PAD")) lds_bytes += (size_t)atoi(pad);      // tuning aid: lowers the occupancy
     const int    occ       = trace_occupancy(filter, lds_table, lds_bytes, block);
     const uint32_t max_grid = (uint32_t)c->num_cu * (uint32_t)occ;
     const uint64_t lanes    = (uint64_t)max_grid * block;

@@ -282,7 +282,14 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
             };
             auto process_lists = [&]() {
                 for (uint32_t e = 0; __ballot(e < cnt); ++e) {
-                    if (e < cnt) exact_test((uint32_t)my_list[e * 64u]);
+                    if (e < cnt) {
+                        uint32_t idx = (uint32_t)my_list[e * 64u];
+                        if (FILTER == kFilterMfma) {       // decode (group, s, bit) -- see the extraction below
+                            const uint32_t pb = 31u - (idx & 31u), gs = ((lane >> 4) + ((idx >> 5) & 3u)) & 3u;
+                            idx = ((idx >> 7) << 7) + ((pb >> 2) << 4) + (gs << 2) + (pb & 3u);
+                        }
+                        exact_test(idx);
+                    }
                 }
                 n_cand += cnt;
                 cnt = 0;
@@ -330,18 +337,25 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 xbuf[lane * 8u + 7u] = oo - kGammaRay * oo;                // |o|^2 minus the per-ray share of the margin
                 const uint32_t g = lane >> 4, q = lane & 15u;
                 s8v   bh[4], bc[4];
-                f4v   ch[4];
                 float ooa[4];
 #pragma unroll
                 for (uint32_t rg = 0; rg < 4u; ++rg) {
                     const uint32_t src = (rg * 16u + q) * 8u;
-                    const float vh = (g < 3u) ? xbuf[src + g] : 0.0f;       // h = C.d' (+ the -o.d' accumulator below)
-                    const float vc = (g < 3u) ? xbuf[src + 3u + g] : 1.0f;  // c = -2 o.C + K'' * 1
-                    const float mo = xbuf[src + 6u];
+                    const float vh = (g < 3u) ? xbuf[src + g] : xbuf[src + 6u];   // d' component, or -o.d' for lane group 3
+                    const float vc = (g < 3u) ? xbuf[src + 3u + g] : 1.0f;        // c = -2 o.C + K'' * 1
                     ooa[rg] = xbuf[src + 7u];
-                    bh[rg]  = split_ray_operand(vh);
                     bc[rg]  = split_ray_operand(vc);
-                    ch[rg]  = f4v{ mo, mo, mo, mo };
+                    // Lane group 3 of the h form: the sphere side holds 1.0 in k-slots 1, 3 and 4 of that group (they
+                    // meet zeros of the c form), so -o.d' enters the sum as three exact products p_k * 1.0 and the
+                    // MFMA needs no accumulator input.
+                    const s8v hs = split_ray_operand(vh);
+                    const uint32_t u1 = __float_as_uint(vh) & 0xFFFF0000u;
+                    const float    r1 = vh - __uint_as_float(u1);
+                    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
+                    const float    r2 = r1 - __uint_as_float(u2);
+                    const uint32_t u3 = __float_as_uint(r2) & 0xFFFF0000u;
+                    uint4 k3; k3.x = u1; k3.y = u2; k3.z = u3 >> 16; k3.w = 0u;   // (0,p1, 0,p2, p3,0, 0,0)
+                    bh[rg] = (g < 3u) ? hs : __builtin_bit_cast(s8v, k3);
                 }
                 const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t: tabA[t * 64]
 
@@ -353,20 +367,21 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     for (uint32_t tt = 0; tt < 8u; ++tt) {
                         const s8v A = A_next;
                         A_next = __builtin_bit_cast(s8v, tabA[((base >> 4) + tt + 1u) * 64u]);   // the table ends with a spare tile
-                        f4v h[4], w[4];
+                        const f4v zero = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-                        for (uint32_t rg = 0; rg < 4u; ++rg) h[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rg], ch[rg], 0, 0, 0);
+                        for (uint32_t rp = 0; rp < 4u; rp += 2u) {          // two ray groups in flight
+                            f4v h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rp], zero, 0, 0, 0);
+                            f4v h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rp + 1u], zero, 0, 0, 0);
 #pragma unroll
-                        for (uint32_t rg = 0; rg < 4u; ++rg) {
+                            for (int j = 0; j < 4; ++j) h0[j] = __builtin_fmaf(-h0[j], h0[j], ooa[rp]);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) w[rg][j] = __builtin_fmaf(-h[rg][j], h[rg][j], ooa[rg]);
-                        }
+                            for (int j = 0; j < 4; ++j) h1[j] = __builtin_fmaf(-h1[j], h1[j], ooa[rp + 1u]);
+                            h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rp], h0, 0, 0, 0);
+                            h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rp + 1u], h1, 0, 0, 0);
 #pragma unroll
-                        for (uint32_t rg = 0; rg < 4u; ++rg) w[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rg], w[rg], 0, 0, 0);
+                            for (int j = 0; j < 4; ++j) mk[rp] = __builtin_amdgcn_alignbit(mk[rp], __float_as_uint(h0[j]), 31u);
 #pragma unroll
-                        for (uint32_t rg = 0; rg < 4u; ++rg) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) mk[rg] = __builtin_amdgcn_alignbit(mk[rg], __float_as_uint(w[rg][j]), 31u);
+                            for (int j = 0; j < 4; ++j) mk[rp + 1u] = __builtin_amdgcn_alignbit(mk[rp + 1u], __float_as_uint(h1[j]), 31u);
                         }
                     }
                     RTX_STAMP(2);
@@ -376,26 +391,39 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
 #pragma unroll
                     for (uint32_t s = 0; s < 4u; ++s) {
                         const uint32_t sel = (g - s) & 3u;
-                        word[s] = sel == 0u ? mk[0] : (sel == 1u ? mk[1] : (sel == 2u ? mk[2] : mk[3]));
+                        const uint32_t lo  = (sel & 1u) ? mk[1] : mk[0];
+                        const uint32_t hi  = (sel & 1u) ? mk[3] : mk[2];
+                        word[s] = (sel & 2u) ? hi : lo;
                     }
 #pragma unroll
                     for (uint32_t s = 1; s < 4u; ++s)
                         word[s] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((((g + s) & 3u) << 4) + q) << 2), (int)word[s]);
                     if (!tracing) { word[0] = 0; word[1] = 0; word[2] = 0; word[3] = 0; }
-                    // bit 31 - (4 tt + j) of the word from group gs  <->  sphere base + 16 tt + 4 gs + j.  Each round takes
-                    // one candidate out of each of the four words, branch-free (an empty word stores a dummy entry
-                    // that the unchanged count leaves dead), so a round costs one ballot whatever the lanes hold.
-                    while (__ballot((word[0] | word[1] | word[2] | word[3]) != 0)) {
-                        if (__ballot(cnt + 4u > kListCap)) process_lists();
+                    // A list entry is the code (group << 7) | (s << 5) | bit, decoded by the owner in exact_test: bit b
+                    // (from the LSB) of the word from lane group gs = (g + s) & 3 is sphere base + 16 tt + 4 gs + j with
+                    // 4 tt + j = 31 - b.  First the lowest candidate of each word, branch-free (an empty word stores a
+                    // dead entry: the count does not move); then the rare leftovers, one per lane and round.
+                    if (__ballot(cnt + 4u > kListCap)) process_lists();
+                    const uint32_t grp_code = (base >> 7) << 7;
 #pragma unroll
-                        for (uint32_t s = 0; s < 4u; ++s) {
-                            const uint32_t wv   = word[s];
-                            const uint32_t pbit = 31u - (uint32_t)__builtin_ctz(wv | 0x80000000u) ;   // position from the top; any value when wv == 0
-                            const uint32_t gs   = (g + s) & 3u;
-                            my_list[cnt * 64u] = (list_t)(base + ((pbit >> 2) << 4) + (gs << 2) + (pbit & 3u));
-                            cnt += (wv != 0u) ? 1u : 0u;
-                            word[s] = wv & (wv - 1u);
-                        }
+                    for (uint32_t s = 0; s < 4u; ++s) {
+                        const uint32_t wv = word[s];
+                        my_list[cnt * 64u] = (list_t)((grp_code | (s << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
+                        cnt += (wv != 0u) ? 1u : 0u;
+                        word[s] = wv & (wv - 1u);
+                    }
+                    while (__ballot((word[0] | word[1] | word[2] | word[3]) != 0)) {
+                        if (__ballot(cnt == kListCap)) process_lists();
+                        const bool     n0 = word[0] != 0u, n1 = word[1] != 0u, n2 = word[2] != 0u;
+                        const uint32_t sl = n0 ? 0u : (n1 ? 1u : (n2 ? 2u : 3u));
+                        const uint32_t wv = n0 ? word[0] : (n1 ? word[1] : (n2 ? word[2] : word[3]));
+                        my_list[cnt * 64u] = (list_t)((grp_code | (sl << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
+                        cnt += (wv != 0u) ? 1u : 0u;
+                        const uint32_t cl = wv & (wv - 1u);
+                        word[0] = n0 ? cl : word[0];
+                        word[1] = (!n0 && n1) ? cl : word[1];
+                        word[2] = (!n0 && !n1 && n2) ? cl : word[2];
+                        word[3] = (!n0 && !n1 && !n2) ? cl : word[3];
                     }
                     RTX_STAMP(9);
                 }
