@@ -42,6 +42,9 @@ struct rtx_ctx {
     // scene
     uint32_t n = 0, n_pad = 0, n_pad_mfma = 0;
     int      filter = kFilterMfma;
+    bool     mfma_ok = false;       // the scene fits the f16 range of the MFMA filter
+    float    mfma_scale = 1.0f;
+    double   mfma_omax = 0.0;       // largest |component| of a ray origin the MFMA filter's f16 operands can carry
     float4*  hot = nullptr;
     float4*  hot_mfma = nullptr;
     float4*  exact = nullptr;
@@ -132,40 +135,58 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
             hot[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0e30f);   // padding: never a candidate
         }
     }
-    // MFMA filter: per 16-sphere tile, lane (g = lane >> 4, r = lane & 15) holds component g of sphere 16 t + r as the
-    // eight bf16 (s1,s1,s2,s1,s2,s3,s2,s3) of its exact three-way split; component 3 is K'' = |C|^2 - r^2 - margin.
+    // MFMA filter: per 32-sphere tile, lane (hf = lane >> 5, r = lane & 31) holds, for sphere 32 t + r, the eight f16
+    // k-slots of components 2 hf and 2 hf + 1: (x1,x1,x2,x2) of the two-way split of scale * cx, cy (hf 0) or of
+    // scale * cz followed by (1, 1, K1, K2), K = scale^2 K'' 2^-15, K'' = |C|^2 - r^2 - margin (hf 1).  `scale` is the
+    // largest power of two that keeps every sphere-side value, every ray origin on a sphere (|o| <= |C| + r) and K
+    // inside the f16 range; the camera origin is checked against the same bound per launch (else the VALU filter runs).
     const uint32_t n_pad_mfma = (n + 127u) & ~127u;
-    std::vector<uint4> tabA(((size_t)n_pad_mfma + 16u) * 4u);      // + one spare tile: the kernel prefetches one tile ahead
-    auto split3 = [](float x, uint32_t h[3]) {
-        float rem = x;
-        for (int k = 0; k < 3; ++k) {
-            uint32_t u; memcpy(&u, &rem, 4); u &= 0xFFFF0000u;
-            float part; memcpy(&part, &u, 4);
-            h[k] = u >> 16;
-            rem -= part;                      // exact: part is the truncation of rem
+    double max_c = 0.0, max_o = 0.0, max_k = 0.0;
+    bool   finite = true;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double comp[3] = { std::fabs((double)cx[i]), std::fabs((double)cy[i]), std::fabs((double)cz[i]) };
+        const double r = std::fabs((double)radius[i]);
+        finite = finite && std::isfinite(comp[0]) && std::isfinite(comp[1]) && std::isfinite(comp[2]) && std::isfinite(r);
+        const double C2 = comp[0] * comp[0] + comp[1] * comp[1] + comp[2] * comp[2], r2 = r * r;
+        for (double v : comp) { max_c = std::max(max_c, v); max_o = std::max(max_o, v + 1.01 * r); }
+        max_k = std::max(max_k, (1.0 + 3.0 * kGammaSphere) * (C2 + r2));
+    }
+    int exp2 = 40;
+    if (finite && n > 0) {
+        while (exp2 > -40) {
+            const double sgm = std::ldexp(1.0, exp2);
+            if (sgm * max_c <= 60000.0 && 2.0 * sgm * max_o <= 60000.0 && sgm * sgm * max_k * std::ldexp(1.0, -15) + std::ldexp(1.0, -9) <= 60000.0) break;
+            --exp2;
         }
+    } else {
+        exp2 = 0;
+    }
+    const bool   mfma_ok = finite && exp2 > -40;
+    const double sgm = std::ldexp(1.0, mfma_ok ? exp2 : 0);
+    std::vector<uint4> tabA(((size_t)n_pad_mfma + 32u) * 2u);      // + one spare tile: the kernel prefetches one tile ahead
+    auto split2 = [](double x) -> uint32_t {                        // (x1 | x2 << 16), round to nearest
+        const _Float16 x1 = (_Float16)x;
+        const _Float16 x2 = (_Float16)(x - (double)x1);
+        uint16_t a, b; memcpy(&a, &x1, 2); memcpy(&b, &x2, 2);
+        return (uint32_t)a | ((uint32_t)b << 16);
     };
-    for (uint32_t i = 0; i < n_pad_mfma + 16u; ++i) {
-        float comp[4] = { 0.0f, 0.0f, 0.0f, 1.0e30f };           // padding: c = 1e30 + ..., never negative
-        if (i < n) {
+    auto dup = [](uint32_t lohi, int which) -> uint32_t { const uint32_t h = which ? (lohi >> 16) : (lohi & 0xFFFFu); return h | (h << 16); };
+    for (uint32_t i = 0; i < n_pad_mfma + 32u; ++i) {
+        uint32_t px = 0, py = 0, pz = 0, pk;
+        if (i < n && mfma_ok) {
             const double C2 = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
             const double r2 = (double)radius[i] * radius[i];
             const double Kp = C2 - r2;
-            const double Kpp = Kp - kGammaSphere * (C2 + r2 + std::fabs(Kp));
-            comp[0] = cx[i]; comp[1] = cy[i]; comp[2] = cz[i];
-            comp[3] = std::nextafter((float)Kpp, -INFINITY);       // rounded towards "more candidates"
+            const double Kpp = Kp - kGammaSphere * (C2 + r2 + std::fabs(Kp)) - std::ldexp(1.0, -9) / (sgm * sgm);
+            px = split2(sgm * cx[i]); py = split2(sgm * cy[i]); pz = split2(sgm * cz[i]);
+            pk = split2(sgm * sgm * Kpp * std::ldexp(1.0, -15));
+        } else {
+            pk = split2(60000.0);                                    // padding: c = 60000 * 2^15 + ..., never negative
         }
-        const uint32_t t = i >> 4, r = i & 15u;
-        for (uint32_t g = 0; g < 4u; ++g) {
-            uint32_t h[3];
-            split3(comp[g], h);
-            // groups 0..2 (cx, cy, cz): (s1,s1, s2,s1, s2,s3, s2,s3); group 3 (K''): (s1,ONE, s2,ONE, ONE,s3, 0,0) -- the
-            // ONEs carry the ray's -o.d' into the h form, where K'' meets zeros, and meet zeros in the c form
-            const uint32_t ONE = 0x3F80u;
-            tabA[(size_t)t * 64u + g * 16u + r] = (g < 3u)
-                ? make_uint4(h[0] | (h[0] << 16), h[1] | (h[0] << 16), h[1] | (h[2] << 16), h[1] | (h[2] << 16))
-                : make_uint4(h[0] | (ONE << 16), h[1] | (ONE << 16), ONE | (h[2] << 16), 0u);
-        }
+        const uint32_t t = i >> 5, r = i & 31u;
+        const uint32_t ONE2 = 0x3C003C00u;                           // (1.0, 1.0): carries the ray's -scale o.d' into the h form
+        tabA[(size_t)t * 64u + r]       = make_uint4(dup(px, 0), dup(px, 1), dup(py, 0), dup(py, 1));
+        tabA[(size_t)t * 64u + 32u + r] = make_uint4(dup(pz, 0), dup(pz, 1), ONE2, pk);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->hot_mfma) (void)hipFree(c->hot_mfma);
@@ -183,6 +204,7 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     HIP_TRY(hipMemcpy(c->exact, exact.data(), exact.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat, mat.data(), mat.size() * sizeof(uint4), hipMemcpyHostToDevice));
     c->n = n; c->n_pad = n_pad; c->n_pad_mfma = n_pad_mfma; c->have_scene = true;
+    c->mfma_ok = mfma_ok; c->mfma_scale = (float)sgm; c->mfma_omax = 30000.0 / sgm;
     return RTX_OK;
 }
 
@@ -250,7 +272,16 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     }
 
     const bool   validate  = (flags & RTX_FLAG_VALIDATE_FILTER) != 0;
-    const int    filter    = c->filter;
+    int          filter    = c->filter;
+    if (filter == kFilterMfma) {
+        // primary rays start on the lens (camera.h:75-86); bounce rays start on spheres, which the scale already covers
+        bool fits = c->mfma_ok;
+        for (int k = 0; k < 3 && fits; ++k) {
+            const double reach = std::fabs((double)c->cam.origin[k]) + std::fabs((double)c->cam.lens_radius) * (std::fabs((double)c->cam.u[k]) + std::fabs((double)c->cam.v[k]));
+            fits = std::isfinite(reach) && reach <= c->mfma_omax;
+        }
+        if (!fits) filter = kFilterValu;
+    }
     const bool   lds_table = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
     uint32_t block = 256u;
     if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) block = (uint32_t)v; }
@@ -281,7 +312,7 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     }
 
     TraceParams P{};
-    P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
+    P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.mfma_scale = c->mfma_scale; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
     P.cols = cols; P.rows = rows; P.npix = npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = nchunks;
     P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = n_items;
     P.partials = c->partials; P.primary = want_primary ? c->primary : nullptr; P.work_counter = c->work_counter;

@@ -17,21 +17,26 @@ constexpr uint32_t kMaxBlock   = 512;                  // threads per workgroup 
 constexpr uint32_t kWaveBatch  = 256;                  // work items a wave reserves per trip to the global counter
 constexpr uint32_t kListCap    = 16;                   // per-lane candidate list entries (LDS), flushed when full
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
-// MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) per sphere and gamma * |o|^2 per ray, gamma = 2^-17.
-// It covers (5 kappa + 16) ulp * (|C|^2 + |o|^2) with kappa = 16, three times the worst accumulation error observed
-// for v_mfma_f32_16x16x32_bf16 (5.3 ulp of sum |terms|, tools/microbench/mfma_bf16_error.hip).
-constexpr float    kGammaRay   = 7.62939453125e-06f * 1.0625f;   // 2^-17 plus room for the rounding of |o|^2 itself
-constexpr double   kGammaSphere = 7.62939453125e-06;
+// MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) + 2^-9 / scale^2 per sphere and gamma * |o|^2 per ray,
+// gamma = 2^-16 = 256 ulp (ulp = 2^-24).  Budget, in ulp of (|C|^2 + |o|^2): the two-way f16 split leaves 2^-22 per
+// operand, i.e. 8 ulp per product; with d' itself (4), -o.d' (4) and the accumulation of v_mfma_f32_32x32x16_f16
+// (<= 5.7 ulp of sum |terms|, tools/microbench/mfma_f16_error.hip) h is off by <= 24 ulp (|C| + |o|), h^2 by <= 96;
+// the c form adds 8 (split of -2 o.C) + 4 (K'') + 17 (accumulation on top of |o|^2 - h^2); the reference's own rounding
+// of b*b - a*c moves the sign within 34 ulp.  Sum 159 of 256.  The 2^-9 / scale^2 term covers f16 subnormals (x2 parts
+// below 2^-14 are rounded to multiples of 2^-24; the largest effect is K2 against the ray side's 2^15).
+constexpr float    kGammaRay   = 1.52587890625e-05f * 1.0625f;   // 2^-16 plus room for the rounding of |o|^2 itself
+constexpr double   kGammaSphere = 1.52587890625e-05;
 enum FilterKind { kFilterValu = 0, kFilterMfma = 1 };
 constexpr uint32_t kMaxLdsSpheres = 2048;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
-constexpr uint32_t kMaxLdsSpheresMfma = 1024;          // MFMA filter: 64 B/sphere
+constexpr uint32_t kMaxLdsSpheresMfma = 1024;          // MFMA filter: 32 B/sphere (+ 16 B exact record)
 
 enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStFilterMiss, kStCount };
 
 struct TraceParams {
     const float4* hot;      // n_pad x (cx, cy, cz, -(r^2 (1+eps)))  -- the VALU filter's view of a sphere
-    const float4* hot_mfma; // n_pad_mfma/16 tiles x 64 lanes x 16 B: bf16 A operands (cx, cy, cz, K'') of the MFMA filter
+    const float4* hot_mfma; // (n_pad_mfma/32 + 1) tiles x 64 lanes x 16 B: f16 A operands (cx, cy, cz, K'') of the MFMA filter
     uint32_t      n_pad_mfma;
+    float         mfma_scale; // power of two applied to the sphere side of the MFMA filter (f16 range)
     const float4* exact;    // n x (cx, cy, cz, r)                   -- sphere.h:24-28 geometry, as uploaded
     const uint4*  mat;      // 2n: [2i] = (type, albedo r, g, b), [2i+1] = (blur, ior, 0, 0), float bits
     uint32_t      n, n_pad;

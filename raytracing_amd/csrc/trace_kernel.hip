@@ -103,29 +103,22 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 
 enum LaneState : uint32_t { kNeedItem = 0, kNeedSample = 1, kTrace = 2, kDead = 3 };
 
-#ifndef RTX_MFMA_TILE_UNROLL
-#define RTX_MFMA_TILE_UNROLL 2
-#endif
-typedef short s8v __attribute__((ext_vector_type(8)));
-typedef float f4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 
-// Exact three-way split of an f32 into bf16 parts by truncation (x == p1 + p2 + p3), laid out for the ray (B) side
-// of the MFMA: elements (p1,p2,p1,p3,p2,p1,p3,p2) meet the sphere side's (s1,s1,s2,s1,s2,s3,s2,s3), i.e. every
-// partial product except s3*p3.
-__device__ __forceinline__ s8v split_ray_operand(float x)
+// Two-way f16 split of an f32 (round to nearest): x = x1 + x2 + e with |e| <= 2^-22 |x| (or 2^-25 once x2 is subnormal).
+// Returns x1 in the low and x2 in the high half: the ray (B) side's k-slot pattern (p1, p2, p1, p2) is this dword twice,
+// meeting the sphere side's (s1, s1, s2, s2).
+__device__ __forceinline__ uint32_t split_f16_pair(float x)
 {
-    const uint32_t u1 = __float_as_uint(x) & 0xFFFF0000u;
-    const float    r1 = x - __uint_as_float(u1);
-    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float    r2 = r1 - __uint_as_float(u2);
-    const uint32_t u3 = __float_as_uint(r2) & 0xFFFF0000u;
-    const uint32_t h1 = u1 >> 16, h2 = u2 >> 16, h3 = u3 >> 16;
-    uint4 w;
-    w.x = h1 | u2;            // (p1, p2)
-    w.y = h1 | u3;            // (p1, p3)
-    w.z = h2 | u1;            // (p2, p1)
-    w.w = h3 | u2;            // (p3, p2)
-    return __builtin_bit_cast(s8v, w);
+    const _Float16 x1 = (_Float16)x;
+    const float    r  = x - (float)x1;          // exact
+    h2v p;
+    p[0] = x1;
+    p[1] = (_Float16)r;
+    return __builtin_bit_cast(uint32_t, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -139,9 +132,9 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     typedef typename std::conditional<LDS_TABLE, uint16_t, uint32_t>::type list_t;
 
     // (1) stage the filter's sphere table into LDS once per workgroup (16 B per sphere for the VALU filter,
-    //     64 B per sphere -- the bf16 A operands of 16-sphere tiles -- for the MFMA filter)
+    //     32 B per sphere -- the f16 A operands of 32-sphere tiles, plus one spare tile -- for the MFMA filter)
     const float4* table = (FILTER == kFilterMfma) ? P.hot_mfma : P.hot;
-    const uint32_t table_f4 = (FILTER == kFilterMfma) ? P.n_pad_mfma * 4u : P.n_pad;
+    const uint32_t table_f4 = (FILTER == kFilterMfma) ? (P.n_pad_mfma + 32u) * 2u : P.n_pad;
     list_t* lists;
     const float4* exact = P.exact;
     if (LDS_TABLE) {
@@ -285,8 +278,8 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     if (e < cnt) {
                         uint32_t idx = (uint32_t)my_list[e * 64u];
                         if (FILTER == kFilterMfma) {       // decode (group, s, bit) -- see the extraction below
-                            const uint32_t pb = 31u - (idx & 31u), gs = ((lane >> 4) + ((idx >> 5) & 3u)) & 3u;
-                            idx = ((idx >> 7) << 7) + ((pb >> 2) << 4) + (gs << 2) + (pb & 3u);
+                            const uint32_t pb = 31u - (idx & 31u), sl = (idx >> 5) & 3u;
+                            idx = ((idx >> 7) << 7) + ((sl >> 1) << 6) + ((pb >> 4) << 5) + (((pb & 15u) >> 2) << 3) + ((sl & 1u) << 2) + (pb & 3u);
                         }
                         exact_test(idx);
                     }
@@ -324,85 +317,79 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     }
                 }
             } else {
-                // ---- MFMA filter.  Lane (g = lane >> 4, q = lane & 15) of ray group rg works on ray 16 rg + q:
-                // it feeds component g of that ray into k-slots 8g..8g+7 and receives the results of spheres
-                // 4g..4g+3 of every 16-sphere tile.  Each ray's owner first publishes its filter quantities.
+                // ---- MFMA filter: v_mfma_f32_32x32x16_f16 on two-way f16 splits (x = x1 + x2, 22 bits).  A tile is 32
+                // spheres x 32 rays with K = 16 = 4 components (cx, cy, cz, K''/-o.d') x the 4 partial products
+                // x1 p1, x1 p2, x2 p1, x2 p2.  Lane (hf = lane >> 5, c = lane & 31) feeds k-slots 8 hf .. 8 hf + 7
+                // (components 2 hf, 2 hf + 1) of ray c (first MFMA) and ray 32 + c (second MFMA), and receives, for each
+                // of the two rays, the results of spheres 8 b + 4 hf + j (v = 4 b + j) of the tile.  The sphere side is
+                // pre-scaled by sg = P.mfma_scale (a power of two that puts the scene into f16 range), so the h form
+                // yields sg h and everything after it carries sg^2.  Each ray's owner first publishes its quantities.
                 const float rs = __builtin_amdgcn_rsqf(a);
                 const float fx = d.x * rs, fy = d.y * rs, fz = d.z * rs;
                 const float od = __builtin_fmaf(o.z, fz, __builtin_fmaf(o.y, fy, o.x * fx));
                 const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
-                xbuf[lane * 8u + 0u] = fx;  xbuf[lane * 8u + 1u] = fy;  xbuf[lane * 8u + 2u] = fz;
-                xbuf[lane * 8u + 3u] = -2.0f * o.x; xbuf[lane * 8u + 4u] = -2.0f * o.y; xbuf[lane * 8u + 5u] = -2.0f * o.z;
-                xbuf[lane * 8u + 6u] = -od;
-                xbuf[lane * 8u + 7u] = oo - kGammaRay * oo;                // |o|^2 minus the per-ray share of the margin
-                const uint32_t g = lane >> 4, q = lane & 15u;
-                s8v   bh[4], bc[4];
-                float ooa[4];
+                const float sg = P.mfma_scale, m2s = -2.0f * sg;
+                float4* const xbuf4 = reinterpret_cast<float4*>(xbuf);
+                xbuf4[lane * 2u]      = make_float4(fx, fy, m2s * o.x, m2s * o.y);
+                xbuf4[lane * 2u + 1u] = make_float4(fz, -sg * od, m2s * o.z, (sg * sg) * (oo - kGammaRay * oo));   // |o|^2 minus the ray's share of the margin
+                const uint32_t hf = lane >> 5, cl = lane & 31u;
+                h8v   bh[2], bc[2];
+                float ooa[2];
 #pragma unroll
-                for (uint32_t rg = 0; rg < 4u; ++rg) {
-                    const uint32_t src = (rg * 16u + q) * 8u;
-                    const float vh = (g < 3u) ? xbuf[src + g] : xbuf[src + 6u];   // d' component, or -o.d' for lane group 3
-                    const float vc = (g < 3u) ? xbuf[src + 3u + g] : 1.0f;        // c = -2 o.C + K'' * 1
-                    ooa[rg] = xbuf[src + 7u];
-                    bc[rg]  = split_ray_operand(vc);
-                    // Lane group 3 of the h form: the sphere side holds 1.0 in k-slots 1, 3 and 4 of that group (they
-                    // meet zeros of the c form), so -o.d' enters the sum as three exact products p_k * 1.0 and the
-                    // MFMA needs no accumulator input.
-                    const s8v hs = split_ray_operand(vh);
-                    const uint32_t u1 = __float_as_uint(vh) & 0xFFFF0000u;
-                    const float    r1 = vh - __uint_as_float(u1);
-                    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
-                    const float    r2 = r1 - __uint_as_float(u2);
-                    const uint32_t u3 = __float_as_uint(r2) & 0xFFFF0000u;
-                    uint4 k3; k3.x = u1; k3.y = u2; k3.z = u3 >> 16; k3.w = 0u;   // (0,p1, 0,p2, p3,0, 0,0)
-                    bh[rg] = (g < 3u) ? hs : __builtin_bit_cast(s8v, k3);
+                for (uint32_t half = 0; half < 2u; ++half) {
+                    const uint32_t ray = half * 32u + cl;
+                    const float4   v   = xbuf4[ray * 2u + hf];
+                    ooa[half]          = xbuf[ray * 8u + 7u];
+                    const uint32_t pa = split_f16_pair(v.x), pb = split_f16_pair(v.y), pc = split_f16_pair(v.z), pd = split_f16_pair(v.w);
+                    // hf 0: h = (d'x, d'y), c = (-2 sg ox, -2 sg oy).   hf 1: h = (d'z, then -sg o.d' against the sphere
+                    // side's (1, 1, K1, K2)), c = (-2 sg oz, then 2^15 against K1, K2 = sg^2 K'' 2^-15)
+                    uint4 H, C;
+                    H.x = pa; H.y = pa; H.z = pb; H.w = hf ? 0u : pb;
+                    C.x = pc; C.y = pc; C.z = hf ? 0u : pd; C.w = hf ? 0x78007800u : pd;
+                    bh[half] = __builtin_bit_cast(h8v, H);
+                    bc[half] = __builtin_bit_cast(h8v, C);
                 }
                 const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t: tabA[t * 64]
 
                 RTX_STAMP(8);
-                s8v A_next = __builtin_bit_cast(s8v, tabA[0]);
+                h8v A_next = __builtin_bit_cast(h8v, tabA[0]);
                 for (uint32_t base = 0; base < P.n_pad_mfma; base += 128u) {
-                    uint32_t mk[4] = { 0u, 0u, 0u, 0u };
-#pragma unroll RTX_MFMA_TILE_UNROLL
-                    for (uint32_t tt = 0; tt < 8u; ++tt) {
-                        const s8v A = A_next;
-                        A_next = __builtin_bit_cast(s8v, tabA[((base >> 4) + tt + 1u) * 64u]);   // the table ends with a spare tile
-                        const f4v zero = { 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-                        for (uint32_t rp = 0; rp < 4u; rp += 2u) {          // two ray groups in flight
-                            f4v h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rp], zero, 0, 0, 0);
-                            f4v h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh[rp + 1u], zero, 0, 0, 0);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) h0[j] = __builtin_fmaf(-h0[j], h0[j], ooa[rp]);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) h1[j] = __builtin_fmaf(-h1[j], h1[j], ooa[rp + 1u]);
-                            h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rp], h0, 0, 0, 0);
-                            h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bc[rp + 1u], h1, 0, 0, 0);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) mk[rp] = __builtin_amdgcn_alignbit(mk[rp], __float_as_uint(h0[j]), 31u);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) mk[rp + 1u] = __builtin_amdgcn_alignbit(mk[rp + 1u], __float_as_uint(h1[j]), 31u);
-                        }
-                    }
-                    RTX_STAMP(2);
-                    // 4 x 4 transpose among lanes q, q+16, q+32, q+48: the owner of ray 16 g + q collects, from lane
-                    // group gs = (g + s) & 3, the word that group built for ray group g.
                     uint32_t word[4];
 #pragma unroll
-                    for (uint32_t s = 0; s < 4u; ++s) {
-                        const uint32_t sel = (g - s) & 3u;
-                        const uint32_t lo  = (sel & 1u) ? mk[1] : mk[0];
-                        const uint32_t hi  = (sel & 1u) ? mk[3] : mk[2];
-                        word[s] = (sel & 2u) ? hi : lo;
-                    }
+                    for (uint32_t w = 0; w < 2u; ++w) {
+                        uint32_t m0 = 0u, m1 = 0u;
 #pragma unroll
-                    for (uint32_t s = 1; s < 4u; ++s)
-                        word[s] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((((g + s) & 3u) << 4) + q) << 2), (int)word[s]);
+                        for (uint32_t tt = 0; tt < 2u; ++tt) {
+                            const h8v A = A_next;
+                            A_next = __builtin_bit_cast(h8v, tabA[((base >> 5) + 2u * w + tt + 1u) * 64u]);   // the table ends with a spare tile
+                            const f16v zero = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+                            f16v h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bh[0], zero, 0, 0, 0);
+                            f16v h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bh[1], zero, 0, 0, 0);
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) h0[j] = __builtin_fmaf(-h0[j], h0[j], ooa[0]);
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) h1[j] = __builtin_fmaf(-h1[j], h1[j], ooa[1]);
+                            h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bc[0], h0, 0, 0, 0);
+                            h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bc[1], h1, 0, 0, 0);
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(h0[j]), 31u);
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(h1[j]), 31u);
+                        }
+                        // Lanes c and 32 + c trade words (v_permlane32_swap: lanes 32..63 of m0 <-> lanes 0..31 of m1): lane c
+                        // gets what lane 32 + c (hf 1) found for ray c, lane 32 + c what lane c (hf 0) found for ray 32 + c.
+                        // Afterwards, in every lane, sw[0] is hf 0's word and sw[1] hf 1's word for the lane's own ray.
+                        const u2v sw = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
+                        word[2u * w]      = sw[0];
+                        word[2u * w + 1u] = sw[1];
+                    }
+                    RTX_STAMP(2);
                     if (!tracing) { word[0] = 0; word[1] = 0; word[2] = 0; word[3] = 0; }
-                    // A list entry is the code (group << 7) | (s << 5) | bit, decoded by the owner in exact_test: bit b
-                    // (from the LSB) of the word from lane group gs = (g + s) & 3 is sphere base + 16 tt + 4 gs + j with
-                    // 4 tt + j = 31 - b.  First the lowest candidate of each word, branch-free (an empty word stores a
-                    // dead entry: the count does not move); then the rare leftovers, one per lane and round.
+                    // A list entry is the code (group << 7) | (s << 5) | bit, decoded in process_lists: word s = 2 w + hf'
+                    // came from lane half hf' and tiles 2 w, 2 w + 1 of this 128-sphere group; its bit b (from the LSB) was
+                    // pushed p = 31 - b th: tile 2 w + (p >> 4), v = p & 15, sphere row 8 (v >> 2) + 4 hf' + (v & 3).
+                    // First the lowest candidate of each word, branch-free (an empty word stores a dead entry: the count
+                    // does not move); then the rare leftovers, one per lane and round.
                     if (__ballot(cnt + 4u > kListCap)) process_lists();
                     const uint32_t grp_code = (base >> 7) << 7;
 #pragma unroll
@@ -658,7 +645,7 @@ static const void* select_kernel(int filter, bool lds_table, bool validate)
 
 size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block)
 {
-    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 16) * 64 : (size_t)n_pad * 16) : 0;
+    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 32 : (size_t)n_pad * 16) : 0;
     const size_t entry = lds_table ? sizeof(uint16_t) : sizeof(uint32_t);
     const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
     return table + exact + (size_t)(block / 64) * kListCap * 64 * entry;
