@@ -128,28 +128,30 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     extern __shared__ float4 smem[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    // candidate list entries: sphere indices fit 16 bits whenever the table is LDS-resident
-    typedef typename std::conditional<LDS_TABLE, uint16_t, uint32_t>::type list_t;
-
     // (1) stage the filter's sphere table into LDS once per workgroup (16 B per sphere for the VALU filter,
     //     32 B per sphere -- the f16 A operands of 32-sphere tiles, plus one spare tile -- for the MFMA filter)
     const float4* table = (FILTER == kFilterMfma) ? P.hot_mfma : P.hot;
     const uint32_t table_f4 = (FILTER == kFilterMfma) ? (P.n_pad_mfma + 32u) * 2u : P.n_pad;
-    list_t* lists;
+    float4* wave_lds;
     const float4* exact = P.exact;
     if (LDS_TABLE) {
-        // table, then the exact (cx, cy, cz, r) records the candidate re-test reads, then the per-wave lists
+        // table, then the exact (cx, cy, cz, r) records the candidate re-test reads, then the per-wave areas
         for (uint32_t i = threadIdx.x; i < table_f4; i += blockDim.x) smem[i] = table[i];
         for (uint32_t i = threadIdx.x; i < P.n; i += blockDim.x) smem[table_f4 + i] = P.exact[i];
         __syncthreads();
         table = smem;
         exact = smem + table_f4;
-        lists = reinterpret_cast<list_t*>(smem + table_f4 + ((P.n + 3u) & ~3u));
+        wave_lds = smem + table_f4 + ((P.n + 3u) & ~3u);
     } else {
-        lists = reinterpret_cast<list_t*>(smem);
+        wave_lds = smem;
     }
-    list_t* const my_list = lists + wave * (kListCap * 64u) + lane;    // entry e of this lane: my_list[e * 64]
-    float* const  xbuf    = reinterpret_cast<float*>(lists + wave * (kListCap * 64u));   // 2 KB ray exchange area (MFMA filter)
+    // per wave (kWaveLdsBytes): 64 ray records (o, a | d, -) that the candidate re-test gathers from -- the MFMA filter
+    // first uses the same 2 KB to hand its per-ray operands around --, 64 result slots, and the candidate queue
+    wave_lds += wave * (kWaveLdsBytes / 16u);
+    float4* const             rayrec = wave_lds;
+    float* const              xbuf   = reinterpret_cast<float*>(wave_lds);
+    unsigned long long* const res    = reinterpret_cast<unsigned long long*>(wave_lds + 128);
+    uint32_t* const           queue  = reinterpret_cast<uint32_t*>(wave_lds + 160);
 
     // wave-level work reservation: [w_next, w_end) is owned, pf holds the next reservation (lane 0's value)
     uint32_t pf = 0;
@@ -161,9 +163,8 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     // per-lane path state
     uint32_t st = kNeedItem, item = 0, pix = 0, s_cur = 0, s_end = 0, bounce = 0;
     V3       o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1), acc = mk(0, 0, 0);
-    uint32_t n_cand = 0;
     // wave-level counters
-    uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0, c_filter_miss = 0;
+    uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0, c_filter_miss = 0, c_cand = 0;
     uint64_t c_rays = 0;
 
     const V3 cam_o = ld3(P.cam.origin), cam_lc = ld3(P.cam.left_corner), cam_h = ld3(P.cam.horizontal), cam_v = ld3(P.cam.vertical);
@@ -254,47 +255,61 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
         float       closest = 3.402823466e+38f;                           // FLT_MAX, raytracer.cpp:251
         uint32_t    best = kNoHit;
         {
-            uint32_t cnt = 0;
-
+            // Candidates of all 64 rays go through one wave-wide queue of (ray lane << 26 | entry) words, so that the
+            // exact re-test always runs with full lanes: a batch is 64 queue entries, one per lane, whatever rays they
+            // belong to.  The testing lane gathers the ray from its record and folds its result into the ray's slot with
+            // a 64-bit LDS minimum on (t bits << 32 | sphere index).
+            //
             // sphere.cpp:72-99 for one candidate.  Candidates arrive in any order, so instead of relying on the
             // ascending scan of raytracer.cpp:291-300 the tie rule is explicit: the hit distance of sphere i is its
             // first root beyond t_min (the far root is only ever accepted when the near one is <= t_min, because
-            // far >= near), and among equal distances the lowest index wins, exactly as the strict '<' there decides.
-            auto exact_test = [&](uint32_t i) {
-                const float4 s = exact[i];
-                const V3    oc = sub(o, mk(s.x, s.y, s.z));
-                const float bq = dot(oc, d);
-                const float cq = dot(oc, oc) - (s.w * s.w);
-                const float disc = bq * bq - a * cq;
-                if (disc > 0) {
-                    const float sq = sqrtf(disc);
-                    float       t  = (-bq - sq) / a;
-                    if (!(t > 0.001f)) t = (-bq + sq) / a;
-                    if (t > 0.001f && (t < closest || (t == closest && i < best))) { closest = t; best = i; }
-                }
-            };
-            auto process_lists = [&]() {
-                for (uint32_t e = 0; __ballot(e < cnt); ++e) {
-                    if (e < cnt) {
-                        uint32_t idx = (uint32_t)my_list[e * 64u];
-                        if (FILTER == kFilterMfma) {       // decode (group, s, bit) -- see the extraction below
-                            const uint32_t pb = 31u - (idx & 31u), sl = (idx >> 5) & 3u;
-                            idx = ((idx >> 7) << 7) + ((sl >> 1) << 6) + ((pb >> 4) << 5) + (((pb & 15u) >> 2) << 3) + ((sl & 1u) << 2) + (pb & 3u);
-                        }
-                        exact_test(idx);
+            // far >= near), and among equal distances the lowest index wins, exactly as the strict '<' there decides:
+            // that is the minimum of (t, i) in lexicographic order, and t > 0 orders like its bit pattern.
+            uint32_t q_head = 0, q_count = 0;          // wave-uniform
+            res[lane] = 0x7F7FFFFFFFFFFFFFull;         // (FLT_MAX, kNoHit): raytracer.cpp:251
+            auto run_batch = [&](uint32_t nb) {
+                if (lane < nb) {
+                    const uint32_t ent = queue[(q_head + lane) & 127u];
+                    const uint32_t ray = ent >> 26;
+                    uint32_t       i   = ent & 0x03FFFFFFu;
+                    if (FILTER == kFilterMfma) {       // decode (group, s, bit) -- see the extraction below
+                        const uint32_t pb = 31u - (i & 31u), sl = (i >> 5) & 3u;
+                        i = ((i >> 7) << 7) + ((sl >> 1) << 6) + ((pb >> 4) << 5) + (((pb & 15u) >> 2) << 3) + ((sl & 1u) << 2) + (pb & 3u);
+                    }
+                    const float4 r0 = rayrec[ray * 2u], r1 = rayrec[ray * 2u + 1u];
+                    const float4 s  = exact[i];
+                    const V3    ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
+                    const float ra = r0.w;
+                    const V3    oc = sub(ro, mk(s.x, s.y, s.z));
+                    const float bq = dot(oc, rd);
+                    const float cq = dot(oc, oc) - (s.w * s.w);
+                    const float disc = bq * bq - ra * cq;
+                    if (disc > 0) {
+                        const float sq = sqrtf(disc);
+                        float       t  = (-bq - sq) / ra;
+                        if (!(t > 0.001f)) t = (-bq + sq) / ra;
+                        if (t > 0.001f)
+                            __hip_atomic_fetch_min(&res[ray], ((unsigned long long)__float_as_uint(t) << 32) | i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                n_cand += cnt;
-                cnt = 0;
+                q_head += nb;
+                q_count -= nb;
+                c_cand += nb;
             };
-            auto append = [&](uint32_t idx) {
-                my_list[cnt * 64u] = (list_t)idx;
-                cnt++;
+            auto enqueue = [&](bool has, uint32_t entry) {
+                const uint64_t m = __ballot(has);
+                if (m) {
+                    if (q_count >= 64u) run_batch(64u);           // keeps q_count + 64 <= 128
+                    if (has) queue[(q_head + q_count + rank_in(m)) & 127u] = (lane << 26) | entry;
+                    q_count += (uint32_t)__popcll(m);
+                }
             };
 
             if (FILTER == kFilterValu) {
                 const float rs = __builtin_amdgcn_rsqf(a) * (1.0f + kEps);
                 const float fx = d.x * rs, fy = d.y * rs, fz = d.z * rs;
+                rayrec[lane * 2u]      = make_float4(o.x, o.y, o.z, a);
+                rayrec[lane * 2u + 1u] = make_float4(d.x, d.y, d.z, 0.0f);
                 for (uint32_t base = 0; base < P.n_pad; base += 32u) {
                     uint32_t m = 0;
 #pragma unroll
@@ -308,12 +323,9 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     }
                     if (!tracing) m = 0;
                     while (__ballot(m != 0)) {
-                        if (m != 0) {
-                            const uint32_t j = (uint32_t)__clz((int)m);
-                            m &= ~(0x80000000u >> j);
-                            append(base + j);
-                        }
-                        if (__ballot(cnt == kListCap)) process_lists();
+                        const uint32_t j = (uint32_t)__clz((int)(m | 1u));
+                        enqueue(m != 0, base + j);
+                        m &= ~(0x80000000u >> j);
                     }
                 }
             } else {
@@ -350,6 +362,10 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     bc[half] = __builtin_bit_cast(h8v, C);
                 }
                 const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t: tabA[t * 64]
+                // the operands are in registers: the same 2 KB now take the ray records of the exact re-test (a wave's
+                // LDS accesses complete in order)
+                rayrec[lane * 2u]      = make_float4(o.x, o.y, o.z, a);
+                rayrec[lane * 2u + 1u] = make_float4(d.x, d.y, d.z, 0.0f);
 
                 RTX_STAMP(8);
                 h8v A_next = __builtin_bit_cast(h8v, tabA[0]);
@@ -385,27 +401,22 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     }
                     RTX_STAMP(2);
                     if (!tracing) { word[0] = 0; word[1] = 0; word[2] = 0; word[3] = 0; }
-                    // A list entry is the code (group << 7) | (s << 5) | bit, decoded in process_lists: word s = 2 w + hf'
+                    // A queue entry is the code (group << 7) | (s << 5) | bit, decoded in run_batch: word s = 2 w + hf'
                     // came from lane half hf' and tiles 2 w, 2 w + 1 of this 128-sphere group; its bit b (from the LSB) was
                     // pushed p = 31 - b th: tile 2 w + (p >> 4), v = p & 15, sphere row 8 (v >> 2) + 4 hf' + (v & 3).
-                    // First the lowest candidate of each word, branch-free (an empty word stores a dead entry: the count
-                    // does not move); then the rare leftovers, one per lane and round.
-                    if (__ballot(cnt + 4u > kListCap)) process_lists();
+                    // First the lowest candidate of each word; then the rare leftovers, one per lane and round.
                     const uint32_t grp_code = (base >> 7) << 7;
 #pragma unroll
                     for (uint32_t s = 0; s < 4u; ++s) {
                         const uint32_t wv = word[s];
-                        my_list[cnt * 64u] = (list_t)((grp_code | (s << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
-                        cnt += (wv != 0u) ? 1u : 0u;
+                        enqueue(wv != 0u, (grp_code | (s << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
                         word[s] = wv & (wv - 1u);
                     }
                     while (__ballot((word[0] | word[1] | word[2] | word[3]) != 0)) {
-                        if (__ballot(cnt == kListCap)) process_lists();
                         const bool     n0 = word[0] != 0u, n1 = word[1] != 0u, n2 = word[2] != 0u;
                         const uint32_t sl = n0 ? 0u : (n1 ? 1u : (n2 ? 2u : 3u));
                         const uint32_t wv = n0 ? word[0] : (n1 ? word[1] : (n2 ? word[2] : word[3]));
-                        my_list[cnt * 64u] = (list_t)((grp_code | (sl << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
-                        cnt += (wv != 0u) ? 1u : 0u;
+                        enqueue(wv != 0u, (grp_code | (sl << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
                         const uint32_t cl = wv & (wv - 1u);
                         word[0] = n0 ? cl : word[0];
                         word[1] = (!n0 && n1) ? cl : word[1];
@@ -416,7 +427,12 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 }
             }
             RTX_STAMP(2);
-            process_lists();
+            while (q_count) run_batch(q_count < 64u ? q_count : 64u);
+            {
+                const unsigned long long rr = res[lane];
+                closest = __uint_as_float((uint32_t)(rr >> 32));
+                best    = (uint32_t)rr;
+            }
             RTX_STAMP(3);
 
             if (VALIDATE) {
@@ -571,15 +587,13 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
 
     // wave totals -> global statistics
     if (P.stats) {
-        uint32_t v = n_cand;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0) {
             atomicAdd(&P.stats[kStSamples], (unsigned long long)c_samples);
             atomicAdd(&P.stats[kStRays], (unsigned long long)c_rays);
             atomicAdd(&P.stats[kStMiss], (unsigned long long)c_miss);
             atomicAdd(&P.stats[kStAbsorb], (unsigned long long)c_absorb);
             atomicAdd(&P.stats[kStDepth], (unsigned long long)c_depth);
-            atomicAdd(&P.stats[kStCandidates], (unsigned long long)v);
+            atomicAdd(&P.stats[kStCandidates], (unsigned long long)c_cand);
             atomicAdd(&P.stats[kStFilterMiss], (unsigned long long)c_filter_miss);
 #ifdef RTX_PHASE_TIMERS
             for (int k = 0; k < 12; ++k) atomicAdd(&P.stats[kStCount + k], (unsigned long long)ph[k]);
@@ -646,9 +660,8 @@ static const void* select_kernel(int filter, bool lds_table, bool validate)
 size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block)
 {
     const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 32 : (size_t)n_pad * 16) : 0;
-    const size_t entry = lds_table ? sizeof(uint16_t) : sizeof(uint32_t);
     const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
-    return table + exact + (size_t)(block / 64) * kListCap * 64 * entry;
+    return table + exact + (size_t)(block / 64) * kWaveLdsBytes;
 }
 
 int trace_occupancy(int filter, bool lds_table, size_t lds_bytes, uint32_t block)
