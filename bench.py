@@ -46,6 +46,16 @@ def cpu_baseline(table, seconds_budget=15.0):
             "sample": "book1 %dx%d, %d spp, depth %d, 64x64 tile jobs on %d threads (%.1f s)" % (COLS, ROWS, spp, DEPTH, cores, dt)}
 
 
+def measured_traffic():
+    """HBM bytes per trace-kernel launch from the committed PMC passes of this same command (FETCH_SIZE + WRITE_SIZE,
+    corrected as MI355X_MICROARCH.md prescribes; tools/rocpd_summary.py writes the file).  None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "trace_kernel_traffic.json")) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +84,8 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")              # keep RCCL's banner off stdout: rank 0 prints one JSON line
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only mode the host driver supports)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cols, rows, spp = args.cols, args.rows, args.spp
@@ -135,7 +147,7 @@ def main():
                        "parallelism": "spp split x%d + RCCL all-reduce of the float accumulation buffer" % world if world > 1 else "1 GPU",
                        "rays_per_sample": round(stats["rays"] / stats["samples"], 4)},
             "roofline": {"bound": "fp32-valu", "kernel": "trace_kernel", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": measured_traffic(),
                          "kernel_ms": round(trace_avg_ms, 4), "sphere_tests_per_launch": tests, "flop_per_test": FLOP_PER_TEST,
                          "exact_tests_per_launch": stats["candidates"]},
         }
