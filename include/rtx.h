@@ -53,7 +53,9 @@ typedef struct rtx_camera {
 /* rtx_render flags */
 enum {
     RTX_FLAG_ACCUMULATE = 1u << 0,  /* add this call's colour sums to the accumulation buffer instead of replacing it */
-    RTX_FLAG_RECURSIVE  = 1u << 1,  /* the -r semantics of raytracer.cpp:213-240 (absorbed / over-depth paths are black) */
+    RTX_FLAG_RECURSIVE  = 1u << 1,  /* the -r semantics of raytracer.cpp:213-240: absorbed / over-depth paths are black, the ray at
+                                       depth == max_depth is still traced, attenuations are multiplied innermost first (needs a
+                                       per-lane stack of max_depth float4 in device memory, at most 8 GiB in all) */
     RTX_FLAG_VALIDATE_FILTER = 1u << 2 /* debug: also run the reference's full ascending scan (raytracer.cpp:291-300) for
                                        every ray and count disagreements with the filtered result in stats.filter_misses */
 };

@@ -56,6 +56,7 @@ struct rtx_ctx {
     float*   accum = nullptr;  size_t accum_floats = 0;
     bool     accum_borrowed = false;   // caller-owned buffer (rtx_use_accum_buffer)
     float4*  partials = nullptr; size_t partials_items = 0;
+    float4*  att_stack = nullptr; size_t att_stack_items = 0;   // RTX_FLAG_RECURSIVE only
     uint32_t* primary = nullptr; size_t primary_items = 0;
     uint32_t* fb = nullptr; size_t fb_items = 0;
     uint32_t* work_counter = nullptr;
@@ -98,7 +99,7 @@ extern "C" int rtx_destroy(rtx_ctx* c)
     if (!c) return RTX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->accum_borrowed ? nullptr : c->accum, c->partials, c->primary, c->fb, c->work_counter, c->stats };
+    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats };
     for (void* b : bufs) if (b) (void)hipFree(b);
     hipEvent_t evs[] = { c->ev_first, c->ev_last, c->ev_t0, c->ev_t1 };
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -243,7 +244,6 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     if (cols == 0 || rows == 0 || spp_count == 0) return fail(RTX_ERR_ARG, "rtx_render: cols, rows and spp_count must be non-zero");
     if ((uint64_t)cols * rows > (1ull << 28)) return fail(RTX_ERR_ARG, "rtx_render: image of %u x %u exceeds 2^28 pixels", cols, rows);
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_ARG, "rtx_render: sample range overflows 32 bits");
-    if (flags & RTX_FLAG_RECURSIVE) return fail(RTX_ERR_ARG, "rtx_render: RTX_FLAG_RECURSIVE (-r) is not implemented by the HIP backend yet");
     if (flags & ~(uint32_t)(RTX_FLAG_ACCUMULATE | RTX_FLAG_RECURSIVE | RTX_FLAG_VALIDATE_FILTER)) return fail(RTX_ERR_ARG, "rtx_render: unknown flag bits 0x%x", flags);
     HIP_TRY(hipSetDevice(c->device));
 
@@ -262,8 +262,8 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
 
     if (!c->ev_open) { HIP_TRY(hipEventRecord(c->ev_first, c->stream)); c->ev_open = true; }
 
-    if (max_depth == 0) {
-        // raytracer.cpp:250: the bounce loop does not run, _color returns (1,1,1) for every sample
+    if (max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE)) {
+        // raytracer.cpp:250: the bounce loop does not run, _color returns (1,1,1) for every sample (-r still traces the primary ray)
         launch_fill(c->accum, npix * 3, (float)spp_count, accumulate, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_last, c->stream));
@@ -320,6 +320,14 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
 
     HIP_TRY(hipMemsetAsync(c->work_counter, 0, 256, c->stream));
     if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
+    if (flags & RTX_FLAG_RECURSIVE) {
+        // -r multiplies the attenuations innermost first (raytracer.cpp:232), so every lane keeps them until its path ends
+        const uint64_t entries = (uint64_t)std::max<uint32_t>(max_depth, 1u) * max_grid * block;
+        if (entries * sizeof(float4) > (8ull << 30)) return fail(RTX_ERR_ARG, "rtx_render: RTX_FLAG_RECURSIVE with max_depth %u needs a %llu MiB attenuation stack; the limit is 8 GiB", max_depth, (unsigned long long)(entries * sizeof(float4) >> 20));
+        rc = ensure(&c->att_stack, &c->att_stack_items, (size_t)entries);
+        if (rc) return rc;
+        P.att_stack = c->att_stack;
+    }
     const uint32_t blocks_needed = (uint32_t)((n_items64 + block - 1) / block);
     const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(max_grid, blocks_needed));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
@@ -399,7 +407,7 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     rc = rtx_last_kernel_ms(c, &ms);
     if (rc) return rc;
     if (primary_hit_host) {
-        if (max_depth == 0) memset(primary_hit_host, 0xFF, (size_t)cols * rows * spp_count * sizeof(uint32_t));
+        if (max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE)) memset(primary_hit_host, 0xFF, (size_t)cols * rows * spp_count * sizeof(uint32_t));
         else HIP_TRY(hipMemcpy(primary_hit_host, c->primary, (size_t)cols * rows * spp_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     if (stats) {
@@ -412,7 +420,7 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
             for (int k = 0; k < 10 && tot; ++k) fprintf(stderr, "phase %-14s %6.2f %%\n", names[k], 100.0 * (double)h[kStCount + k] / (double)tot);
         }
         memset(stats, 0, sizeof(*stats));
-        if (max_depth == 0) {
+        if (max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE)) {
             stats->samples = (uint64_t)cols * rows * spp_count;
             stats->term_depth = stats->samples;
         } else {

@@ -46,6 +46,7 @@ struct TraceParams {
     uint32_t      max_depth, key0, key1, flags;
     uint32_t      n_items;
     float4*       partials;   // n_items x (sum r, g, b, 0): item = chunk * npix + pixel
+    float4*       att_stack;  // RTX_FLAG_RECURSIVE only: max_depth x (grid * block) attenuations
     uint32_t*     primary;    // NULL or spp_count * npix
     uint32_t*     work_counter;
     unsigned long long* stats; // kStCount counters

@@ -167,6 +167,11 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0, c_filter_miss = 0, c_cand = 0;
     uint64_t c_rays = 0;
 
+    // -r only: per-lane stack of attenuations in global memory, entry k of this lane at att_stack[k * stack_stride]
+    const bool     recursive    = (P.flags & RTX_FLAG_RECURSIVE) != 0u;
+    const size_t   stack_stride = (size_t)gridDim.x * blockDim.x;
+    float4* const  att_stack    = P.att_stack + ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+
     const V3 cam_o = ld3(P.cam.origin), cam_lc = ld3(P.cam.left_corner), cam_h = ld3(P.cam.horizontal), cam_v = ld3(P.cam.vertical);
     const V3 cam_uu = ld3(P.cam.u), cam_vv = ld3(P.cam.v);
 
@@ -547,22 +552,41 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
             } else {
                 ok = false;   // reference: printf + assert(0), material.cu:34-36; uploads reject such tables
             }
-            if (ok) {
-                thr = mul(thr, att);                                      // color *= attenuation
-                o   = hp;
-                d   = nd_;
+            if (recursive && bounce >= P.max_depth) {
+                // -r, raytracer.cpp:230-235: `depth < max_depth` is tested before materialScatter; the path is black
+                ended = true; depth_end = true;
+                thr   = mk(0, 0, 0);
+            } else if (ok) {
+                if (recursive) att_stack[(size_t)bounce * stack_stride] = make_float4(att.x, att.y, att.z, 0.0f);
+                else           thr = mul(thr, att);                       // color *= attenuation
+                o = hp;
+                d = nd_;
                 bounce++;
-                if (bounce >= P.max_depth) { ended = true; depth_end = true; }   // loop bound of raytracer.cpp:250
+                if (!recursive && bounce >= P.max_depth) { ended = true; depth_end = true; }   // loop bound of raytracer.cpp:250
             } else {
                 ended    = true;                                          // break, raytracer.cpp:262-264
                 absorbed = true;
+                if (recursive) thr = mk(0, 0, 0);                         // raytracer.cpp:233-235
             }
         } else if (tracing) {                                             // _background, raytracer.cpp:276-282
             V3    unit = normalized(d);
             float t    = 0.5f * (unit.y + 1.0f);
             V3    bg   = add(scale(1.0f - t, mk(1.0f, 1.0f, 1.0f)), scale(t, mk(0.5f, 0.7f, 1.0f)));
-            thr   = mul(thr, bg);
+            if (!recursive) thr = mul(thr, bg);
+            else            thr = bg;
             ended = true;
+        }
+        if (recursive) {
+            // -r unwinds the recursion: attenuation * (attenuation * (... * background)), innermost product first
+            // (raytracer.cpp:232), which rounds differently from the iterative running product
+            uint32_t k = (tracing && !hit) ? bounce : 0u;
+            while (__ballot(k > 0u)) {
+                if (k > 0u) {
+                    --k;
+                    const float4 at = att_stack[(size_t)k * stack_stride];
+                    thr = mul(mk(at.x, at.y, at.z), thr);
+                }
+            }
         }
         // early-terminated-path accounting: one ballot + popcount per cause, kept in wave-uniform registers
         c_miss   += (uint32_t)__popcll(__ballot(tracing && !hit));

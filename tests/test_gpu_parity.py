@@ -24,15 +24,15 @@ def ctx(ra):
 def _hip_frame(ra, ctx, table, f, chunk):
     ctx.upload_scene(table)
     ctx.set_camera(ra.book_camera(f["cols"], f["rows"]))
-    primary, st = ctx.render(f["cols"], f["rows"], f["spp_begin"], f["spp_count"], f["max_depth"], f["seed"], chunk_spp=chunk, want_primary=True)
+    flags = ra.FLAG_RECURSIVE if f["recursive"] else 0
+    primary, st = ctx.render(f["cols"], f["rows"], f["spp_begin"], f["spp_count"], f["max_depth"], f["seed"], flags=flags, chunk_spp=chunk, want_primary=True)
     return ctx.read_accum(), primary, st
 
 
 def test_golden_frames_bit_exact(ra, ctx, golden_scenes, golden_frames):
-    """Primary-hit indices, colour sums and 8-bit framebuffers equal what the compiled reference produced."""
+    """Primary-hit indices, colour sums and 8-bit framebuffers equal what the compiled reference produced (the -r frame
+    included: raytracer.cpp:213-240 multiplies the attenuations innermost first)."""
     for name, f in golden_frames.items():
-        if f["recursive"]:
-            continue
         accum, primary, st = _hip_frame(ra, ctx, golden_scenes[f["scene"]], f, f["spp_count"])
         if "primary" in f:
             assert (primary == f["primary"]).all(), name
@@ -43,7 +43,8 @@ def test_golden_frames_bit_exact(ra, ctx, golden_scenes, golden_frames):
         assert st["samples"] == f["rows"] * f["cols"] * f["spp_count"]
         assert st["sphere_tests"] == st["rays"] * f["n"]
         assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
-        assert st["rays"] == f["scatter_events"] + st["term_miss"]
+        if not f["recursive"]:
+            assert st["rays"] == f["scatter_events"] + st["term_miss"]
 
 
 @pytest.mark.parametrize("cols,rows,spp,depth,chunk", [(97, 61, 3, 50, 0), (64, 64, 8, 50, 3), (33, 7, 1, 1, 0), (128, 96, 4, 5, 2)])
@@ -60,3 +61,19 @@ def test_against_oracle(ra, ctx, oracle, golden_scenes, cols, rows, spp, depth, 
     for k in ("samples", "rays", "sphere_tests", "term_miss", "term_absorb", "term_depth"):
         assert st[k] == o_st[k], k
     assert (ctx.resolve(spp) == oracle.resolve(o_accum, rows, cols, spp)).all()
+
+
+@pytest.mark.parametrize("cols,rows,spp,depth", [(97, 61, 3, 50), (64, 48, 4, 2), (40, 30, 2, 0)])
+def test_recursive_against_oracle(ra, ctx, oracle, golden_scenes, cols, rows, spp, depth):
+    """-r (raytracer.cpp:213-240): absorbed and over-depth paths are black, the ray at depth == max_depth is still traced,
+    and the product of attenuations is formed innermost first."""
+    table = golden_scenes["book1"]
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    primary, st = ctx.render(cols, rows, 0, spp, depth, 9, flags=ra.FLAG_RECURSIVE, chunk_spp=spp, want_primary=True)
+    accum = ctx.read_accum()
+    o_accum, o_primary, o_st = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, 0, spp, depth, 9, chunk_spp=spp, recursive=True, want_primary=True)
+    assert (primary == o_primary).all()
+    assert (bits(accum) == bits(o_accum)).all()
+    for k in ("samples", "rays", "sphere_tests", "term_miss", "term_absorb", "term_depth"):
+        assert st[k] == o_st[k], k
