@@ -15,7 +15,8 @@ FILTER_VALU, FILTER_MFMA = 0, 1
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_camera", "rtx_render",
            "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
-           "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_version"]
+           "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6",
+           "rtx_version"]
 
 
 class RtxError(RuntimeError):
@@ -73,6 +74,9 @@ def lib():
     L.rtx_scene_capacity.argtypes = [C.c_int]
     L.rtx_random_scene.argtypes = [u64, C.c_int, f32, f32, up, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
     L.rtx_write_ppm.argtypes = [C.c_char_p, u32, u32, up]
+    L.rtx_write_ppm_p6.argtypes = [C.c_char_p, u32, u32, up]
+    L.rtx_save_accum.argtypes = [C.c_void_p, C.c_char_p, u32, u64, u32, u32]
+    L.rtx_load_accum.argtypes = [C.c_void_p, C.c_char_p, up, up, up, P(u64), up, up]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L
@@ -160,9 +164,11 @@ def random_scene(seed=1, grid_half=11, p_diffuse=0.8, p_metal=0.95):
     return np.stack([f[0][:n], f[1][:n], f[2][:n], f[3][:n], t[:n].astype(np.float32), f[4][:n], f[5][:n], f[6][:n], f[7][:n], f[8][:n]], axis=1)
 
 
-def write_ppm(path, cols, rows, framebuffer):
+def write_ppm(path, cols, rows, framebuffer, binary=False):
+    """RayTracing.cpp:152-165 ("P3" text); binary=True writes the same pixels as "P6"."""
     fb = np.ascontiguousarray(framebuffer, dtype=np.uint32)
-    _check(lib().rtx_write_ppm(str(path).encode(), cols, rows, _up(fb)))
+    fn = lib().rtx_write_ppm_p6 if binary else lib().rtx_write_ppm
+    _check(fn(str(path).encode(), cols, rows, _up(fb)))
 
 
 # ---- the backend ---------------------------------------------------------------------------------------------------
@@ -246,6 +252,19 @@ class Context:
         a = np.ascontiguousarray(a, dtype=np.float32)
         _check(lib().rtx_write_accum(self._h, cols, rows, _fp(a), a.size))
         self.cols, self.rows = cols, rows
+
+    def save_accum(self, path, spp_done, seed, max_depth, flags=0):
+        """Checkpoint of a progressive render: the accumulation buffer plus (size, samples done, seed, depth, flags)."""
+        _check(lib().rtx_save_accum(self._h, os.fsencode(path), spp_done, seed, max_depth, flags))
+
+    def load_accum(self, path):
+        """Loads a checkpoint into the accumulation buffer; returns dict(cols, rows, spp_done, seed, max_depth, flags).
+        Continue with render(..., spp_begin=spp_done, flags=flags | FLAG_ACCUMULATE)."""
+        v = [C.c_uint32() for _ in range(5)]
+        seed = C.c_uint64()
+        _check(lib().rtx_load_accum(self._h, os.fsencode(path), C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(seed), C.byref(v[3]), C.byref(v[4])))
+        self.cols, self.rows = v[0].value, v[1].value
+        return {"cols": v[0].value, "rows": v[1].value, "spp_done": v[2].value, "seed": seed.value, "max_depth": v[3].value, "flags": v[4].value}
 
     def resolve(self, spp_total, debug_tile=0):
         fb = np.zeros(self.cols * self.rows, dtype=np.uint32)

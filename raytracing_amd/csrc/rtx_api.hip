@@ -469,6 +469,60 @@ extern "C" int rtx_write_accum(rtx_ctx* c, uint32_t cols, uint32_t rows, const f
     return RTX_OK;
 }
 
+namespace {
+struct AccumHeader {          // little endian on disk, 44 bytes
+    char     magic[8];
+    uint32_t version, cols, rows, spp_done;
+    uint64_t seed;
+    uint32_t max_depth, flags, reserved;
+};
+}
+
+extern "C" int rtx_save_accum(rtx_ctx* c, const char* path, uint32_t spp_done, uint64_t seed, uint32_t max_depth, uint32_t flags)
+{
+    if (!c || !path) return fail(RTX_ERR_ARG, "rtx_save_accum: NULL argument");
+    if (!c->accum || c->cols == 0) return fail(RTX_ERR_STATE, "rtx_save_accum: nothing rendered yet");
+    const size_t n_floats = (size_t)c->cols * c->rows * 3;
+    std::vector<float> host(n_floats);
+    int rc = rtx_read_accum(c, host.data(), n_floats);
+    if (rc) return rc;
+    AccumHeader h{};
+    memcpy(h.magic, "RTXACCUM", 8);
+    h.version = 1; h.cols = c->cols; h.rows = c->rows; h.spp_done = spp_done; h.seed = seed; h.max_depth = max_depth; h.flags = flags;
+    // write next to the target, then rename: a crash mid-write must not destroy the previous checkpoint
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(RTX_ERR_ARG, "rtx_save_accum: cannot open %s", tmp.c_str());
+    const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(host.data(), sizeof(float), n_floats, f) == n_floats;
+    if (fclose(f) != 0 || !ok) { remove(tmp.c_str()); return fail(RTX_ERR_ARG, "rtx_save_accum: short write to %s", tmp.c_str()); }
+    if (rename(tmp.c_str(), path) != 0) return fail(RTX_ERR_ARG, "rtx_save_accum: cannot rename %s to %s", tmp.c_str(), path);
+    return RTX_OK;
+}
+
+extern "C" int rtx_load_accum(rtx_ctx* c, const char* path, uint32_t* cols, uint32_t* rows, uint32_t* spp_done, uint64_t* seed, uint32_t* max_depth, uint32_t* flags)
+{
+    if (!c || !path) return fail(RTX_ERR_ARG, "rtx_load_accum: NULL argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(RTX_ERR_ARG, "rtx_load_accum: cannot open %s", path);
+    AccumHeader h{};
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RTXACCUM", 8) != 0 || h.version != 1) { fclose(f); return fail(RTX_ERR_ARG, "rtx_load_accum: %s is not a version-1 accumulation checkpoint", path); }
+    if (h.cols == 0 || h.rows == 0 || (uint64_t)h.cols * h.rows > (1ull << 28)) { fclose(f); return fail(RTX_ERR_ARG, "rtx_load_accum: %s holds an image of %u x %u", path, h.cols, h.rows); }
+    const size_t n_floats = (size_t)h.cols * h.rows * 3;
+    std::vector<float> host(n_floats);
+    const size_t got = fread(host.data(), sizeof(float), n_floats, f);
+    fclose(f);
+    if (got != n_floats) return fail(RTX_ERR_ARG, "rtx_load_accum: %s is truncated (%zu of %zu floats)", path, got, n_floats);
+    int rc = rtx_write_accum(c, h.cols, h.rows, host.data(), n_floats);
+    if (rc) return rc;
+    if (cols) *cols = h.cols;
+    if (rows) *rows = h.rows;
+    if (spp_done) *spp_done = h.spp_done;
+    if (seed) *seed = h.seed;
+    if (max_depth) *max_depth = h.max_depth;
+    if (flags) *flags = h.flags;
+    return RTX_OK;
+}
+
 extern "C" int rtx_resolve_rgbx8(rtx_ctx* c, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host)
 {
     if (!c || !framebuffer_host) return fail(RTX_ERR_ARG, "rtx_resolve_rgbx8: NULL argument");

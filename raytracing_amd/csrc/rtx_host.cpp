@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <vector>
 #include <cstring>
 
 namespace
@@ -118,6 +119,26 @@ extern "C" int rtx_write_ppm(const char* path, uint32_t cols, uint32_t rows, con
         }
     }
     fflush(f);
+    fclose(f);
+    return RTX_OK;
+}
+
+extern "C" int rtx_write_ppm_p6(const char* path, uint32_t cols, uint32_t rows, const uint32_t* fb)
+{
+    if (!path || !fb) return RTX_ERR_ARG;
+    FILE* f = fopen(path, "wb");
+    if (!f) return RTX_ERR_ARG;
+    fprintf(f, "P6\n%d %d\n255\n", (int)cols, (int)rows);
+    std::vector<unsigned char> row((size_t)cols * 3);
+    for (uint32_t y = 0; y < rows; y++) {
+        for (uint32_t x = 0; x < cols; x++) {
+            const uint32_t rgb = fb[(size_t)y * cols + x];
+            row[3 * (size_t)x + 0] = (unsigned char)(rgb >> 24);
+            row[3 * (size_t)x + 1] = (unsigned char)(rgb >> 16);
+            row[3 * (size_t)x + 2] = (unsigned char)(rgb >> 8);
+        }
+        if (fwrite(row.data(), 1, row.size(), f) != row.size()) { fclose(f); return RTX_ERR_ARG; }
+    }
     fclose(f);
     return RTX_OK;
 }

@@ -20,9 +20,22 @@
 namespace pk
 {
 
+// Options beyond the reference's signature (all optional; the defaults give the reference's one-shot behaviour).
+struct HipRenderOptions {
+    uint64_t    seed = 1;
+    int         device = 0;
+    rtx_stats*  stats = nullptr;         // counters of the last pass
+    unsigned    pass_spp = 0;            // > 0: progressive, this many samples per pass
+    const char* checkpoint = nullptr;    // written after every pass (rtx_save_accum)
+    bool        resume = false;          // continue from `checkpoint` when it exists and matches size, seed, depth and -r
+    // called after every pass with the resolved framebuffer and the samples done so far; return false to stop early
+    bool (*on_pass)(const uint32_t* frameBuffer, unsigned spp_done, void* user) = nullptr;
+    void*       user = nullptr;
+};
+
 inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned rows, unsigned cols, uint32_t* frameBuffer,
-                          unsigned num_aa_samples = 4, unsigned max_ray_depth = 50, unsigned numThreads = 1, unsigned blockSize = 64,
-                          bool debug = false, bool recursive = true, uint64_t seed = 1, int device = 0, rtx_stats* stats = nullptr)
+                          unsigned num_aa_samples, unsigned max_ray_depth, unsigned numThreads, unsigned blockSize,
+                          bool debug, bool recursive, const HipRenderOptions& opt)
 {
     (void)numThreads;
     // the flatten step of raytracer.cpp:76-90, to SoA
@@ -45,15 +58,51 @@ inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned row
     for (int k = 0; k < 7; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
     cam.lens_radius = camera.lensRadius;
 
+    const uint32_t flags = recursive ? RTX_FLAG_RECURSIVE : 0u;
     rtx_ctx* ctx = nullptr;
-    int rc = rtx_create(device, &ctx);
+    int rc = rtx_create(opt.device, &ctx);
     if (rc == RTX_OK) rc = rtx_upload_scene(ctx, (uint32_t)n, cx.data(), cy.data(), cz.data(), rad.data(), type.data(), ar.data(), ag.data(), ab.data(), blur.data(), ior.data());
     if (rc == RTX_OK) rc = rtx_set_camera(ctx, &cam);
-    if (rc == RTX_OK) rc = rtx_render(ctx, cols, rows, 0, num_aa_samples, max_ray_depth, seed, recursive ? RTX_FLAG_RECURSIVE : 0u, 0, nullptr, stats);
-    if (rc == RTX_OK) rc = rtx_resolve_rgbx8(ctx, num_aa_samples, debug ? blockSize : 0u, frameBuffer);
+    unsigned done = 0;
+    if (rc == RTX_OK && opt.resume && opt.checkpoint) {
+        uint32_t c_cols = 0, c_rows = 0, c_done = 0, c_depth = 0, c_flags = 0;
+        uint64_t c_seed = 0;
+        if (rtx_load_accum(ctx, opt.checkpoint, &c_cols, &c_rows, &c_done, &c_seed, &c_depth, &c_flags) == RTX_OK) {
+            if (c_cols == cols && c_rows == rows && c_seed == opt.seed && c_depth == max_ray_depth && c_flags == flags && c_done <= num_aa_samples) {
+                done = c_done;
+                printf("renderSceneHIP: resuming %s at %u of %u samples\n", opt.checkpoint, done, num_aa_samples);
+            } else {
+                printf("renderSceneHIP: %s belongs to another render (size, seed, depth or -r differ); starting over\n", opt.checkpoint);
+            }
+        }
+    }
+    const unsigned pass = opt.pass_spp ? opt.pass_spp : num_aa_samples;
+    bool go_on = true;
+    while (rc == RTX_OK && go_on && done < num_aa_samples) {
+        const unsigned count = (num_aa_samples - done < pass) ? num_aa_samples - done : pass;
+        rc = rtx_render(ctx, cols, rows, done, count, max_ray_depth, opt.seed, flags | (done ? RTX_FLAG_ACCUMULATE : 0u), 0, nullptr, opt.stats);
+        if (rc != RTX_OK) break;
+        done += count;
+        if (opt.checkpoint) rc = rtx_save_accum(ctx, opt.checkpoint, done, opt.seed, max_ray_depth, flags);
+        if (rc == RTX_OK && (opt.on_pass || done == num_aa_samples)) {
+            rc = rtx_resolve_rgbx8(ctx, done, debug ? blockSize : 0u, frameBuffer);
+            if (rc == RTX_OK && opt.on_pass) go_on = opt.on_pass(frameBuffer, done, opt.user);
+        }
+    }
+    if (rc == RTX_OK && done == num_aa_samples && opt.resume) rc = rtx_resolve_rgbx8(ctx, done, debug ? blockSize : 0u, frameBuffer);   // resumed a finished render
     if (rc != RTX_OK) printf("renderSceneHIP: %s\n", rtx_last_error());
     rtx_destroy(ctx);
     return rc;
+}
+
+// The reference's signature (raytracer.h:17-19) plus trailing defaults.
+inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned rows, unsigned cols, uint32_t* frameBuffer,
+                          unsigned num_aa_samples = 4, unsigned max_ray_depth = 50, unsigned numThreads = 1, unsigned blockSize = 64,
+                          bool debug = false, bool recursive = true, uint64_t seed = 1, int device = 0, rtx_stats* stats = nullptr)
+{
+    HipRenderOptions opt;
+    opt.seed = seed; opt.device = device; opt.stats = stats;
+    return renderSceneHIP(scene, camera, rows, cols, frameBuffer, num_aa_samples, max_ray_depth, numThreads, blockSize, debug, recursive, opt);
 }
 
 } // namespace pk

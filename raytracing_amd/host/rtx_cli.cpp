@@ -1,7 +1,9 @@
 // rtx_cli.cpp -- the command line of the reference (RayTracing.cpp:42-180) with the GPU mode added.
 // Keeps -a -b -d -f -m -r -t; adds -g (HIP backend, the default and only renderer here), -w / -h (image size, the
 // reference's COLS / ROWS are compile-time, RayTracing.cpp:23-24), -s (seed), -n book1|glass|scaled (scene variant),
-// -G device.  -c (CUDA) and -i (ISPC) name back ends this build does not contain and are refused.
+// -G device, -p <spp per pass> (progressive: the image file is rewritten after every pass), -k <file> (checkpoint of the
+// float accumulation buffer after every pass), -R (resume from the -k file), -6 (binary P6 instead of P3).
+// -c (CUDA) and -i (ISPC) name back ends this build does not contain and are refused.
 #include "scene_types.h"
 #include "render_scene_hip.h"
 
@@ -72,6 +74,13 @@ int main(int argc, char** argv)
     if (args.cmdOptionExists("-n")) variant = args.getCmdOption("-n");
     int device = 0;
     if (args.cmdOptionExists("-G")) device = std::stoi(args.getCmdOption("-G"));
+    unsigned passSpp = 0;
+    if (args.cmdOptionExists("-p")) passSpp = (unsigned)std::stoi(args.getCmdOption("-p"));
+    std::string checkpoint;
+    if (args.cmdOptionExists("-k")) checkpoint = args.getCmdOption("-k");
+    bool resume = args.cmdOptionExists("-R");
+    if (resume && checkpoint.empty()) { printf("Error: -R needs -k <checkpoint file>.\n"); return -1; }
+    bool binary = args.cmdOptionExists("-6");
 
     Scene* scene = randomScene(seed, variant);
     Camera camera(20, float(cols) / float(rows), 0.1f, 10.0f, vector3(13, 2, 3), vector3(0, 1, 0), vector3(0, 0, 0));   // RayTracing.cpp:107-117
@@ -82,14 +91,25 @@ int main(int argc, char** argv)
     fclose(probe);
 
     rtx_stats st;
+    struct PassCtx { std::string file; unsigned cols, rows, total; bool binary; } pc{ filename, cols, rows, (unsigned)aaSamples, binary };
+    HipRenderOptions opt;
+    opt.seed = seed; opt.device = device; opt.stats = &st; opt.pass_spp = passSpp; opt.resume = resume;
+    opt.checkpoint = checkpoint.empty() ? nullptr : checkpoint.c_str();
+    opt.user = &pc;
+    if (passSpp) opt.on_pass = [](const uint32_t* fb, unsigned done, void* user) -> bool {
+        const PassCtx* p = (const PassCtx*)user;
+        printf("pass done: %u of %u samples\n", done, p->total);
+        fflush(stdout);
+        return (p->binary ? rtx_write_ppm_p6(p->file.c_str(), p->cols, p->rows, fb) : rtx_write_ppm(p->file.c_str(), p->cols, p->rows, fb)) == 0;
+    };
     auto t0 = std::chrono::steady_clock::now();
-    int  rc = renderSceneHIP(*scene, camera, rows, cols, frameBuffer.data(), aaSamples, maxBounce, numThreads, blockSize, debug, recursive, seed, device, &st);
+    int  rc = renderSceneHIP(*scene, camera, rows, cols, frameBuffer.data(), aaSamples, maxBounce, numThreads, blockSize, debug, recursive, opt);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != 0) { delete scene; return -1; }
     printf("renderSceneHIP: %f s (%zu spheres, %u x %u, %d spp, depth %d)\n", sec, scene->objects.size(), cols, rows, aaSamples, maxBounce);
     printf("{\"msamples_per_s\": %.3f, \"mrays_per_s\": %.3f, \"kernel_ms\": %.3f, \"rays\": %llu, \"samples\": %llu}\n",
            st.samples / (st.kernel_ms * 1e3), st.rays / (st.kernel_ms * 1e3), st.kernel_ms, (unsigned long long)st.rays, (unsigned long long)st.samples);
-    rc = rtx_write_ppm(filename.c_str(), cols, rows, frameBuffer.data());
+    rc = binary ? rtx_write_ppm_p6(filename.c_str(), cols, rows, frameBuffer.data()) : rtx_write_ppm(filename.c_str(), cols, rows, frameBuffer.data());
     delete scene;
     return rc == 0 ? 0 : -1;
 }

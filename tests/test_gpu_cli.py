@@ -29,3 +29,19 @@ def test_cli_writes_reference_format_ppm(tmp_path, oracle, golden_scenes):
     # -c / -i name back ends this build does not have
     r = subprocess.run([cli, "-c"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "not available" in r.stdout
+
+
+def test_cli_progressive_resume(tmp_path):
+    """-p / -k / -R / -6: a render stopped after some passes and resumed from its checkpoint ends with the same image file
+    as the uninterrupted progressive render."""
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    base = [cli, "-w", "64", "-h", "40", "-m", "6", "-s", "3", "-p", "2", "-6"]
+    a, b, ck = tmp_path / "a.ppm", tmp_path / "b.ppm", tmp_path / "b.accum"
+    r = subprocess.run(base + ["-a", "6", "-f", str(a)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.count("pass done") == 3, r.stdout + r.stderr
+    r = subprocess.run(base + ["-a", "4", "-f", str(b), "-k", str(ck)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and ck.exists(), r.stdout + r.stderr
+    r = subprocess.run(base + ["-a", "6", "-f", str(b), "-k", str(ck), "-R"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "resuming" in r.stdout and r.stdout.count("pass done") == 1, r.stdout + r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert open(a, "rb").read().startswith(b"P6\n64 40\n255\n")

@@ -141,6 +141,36 @@ def test_write_accum_roundtrip_and_borrowed_buffer(ra, ctx, golden_scenes):
     ctx.use_accum_buffer(0, 0, 0)
 
 
+def test_checkpoint_resume_is_bit_identical(ra, ctx, golden_scenes, tmp_path):
+    """Progressive rendering: 3 passes of 2 spp, with a save / load through a file and a NEW context
+    in the middle, give the very floats of the uninterrupted 3 passes."""
+    cols, rows, depth, seed = 80, 50, 50, 5
+    table = golden_scenes["book1"]
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    for k in range(3):
+        ctx.render(cols, rows, 2 * k, 2, depth, seed, flags=ra.FLAG_ACCUMULATE if k else 0, chunk_spp=2)
+    straight = ctx.read_accum()
+    ctx.render(cols, rows, 0, 2, depth, seed, chunk_spp=2)
+    ck = tmp_path / "frame.accum"
+    ctx.save_accum(ck, 2, seed, depth)
+    other = ra.Context(0)
+    try:
+        other.upload_scene(table)
+        other.set_camera(ra.book_camera(cols, rows))
+        info = other.load_accum(ck)
+        assert info == {"cols": cols, "rows": rows, "spp_done": 2, "seed": seed, "max_depth": depth, "flags": 0}
+        for k in (1, 2):
+            other.render(cols, rows, 2 * k, 2, depth, seed, flags=ra.FLAG_ACCUMULATE, chunk_spp=2)
+        assert (other.read_accum().view(np.uint32) == straight.view(np.uint32)).all()
+        with pytest.raises(ra.RtxError, match="checkpoint"):
+            bad = tmp_path / "bad.accum"
+            bad.write_bytes(b"not a checkpoint at all, just forty-four bytes..")
+            other.load_accum(bad)
+    finally:
+        other.close()
+
+
 def test_argument_errors(ra, ctx, golden_scenes):
     with pytest.raises(ra.RtxError, match="upload a scene"):
         ctx.render(8, 8, 0, 1, 5, 1)

@@ -97,6 +97,15 @@ def test_ppm_writer_format(ra, tmp_path):
     assert lines[9] == ""
 
 
+def test_ppm_p6_writer(ra, tmp_path):
+    fb = np.array([0x01020300, 0xFFFEFD00, 0x00000000, 0x80402000, 0x0A0B0CFF, 0x7F7F7F00], dtype=np.uint32)
+    p = tmp_path / "out6.ppm"
+    ra.write_ppm(p, 3, 2, fb, binary=True)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"P6\n3 2\n255\n")
+    assert raw[len(b"P6\n3 2\n255\n"):] == bytes([1, 2, 3, 255, 254, 253, 0, 0, 0, 128, 64, 32, 10, 11, 12, 127, 127, 127])
+
+
 def test_spp_partition():
     from raytracing_amd.multi_gpu import spp_range
     for spp, world, begin in [(500, 8, 0), (4096, 8, 0), (10, 4, 3), (3, 8, 0), (1, 1, 9)]:
