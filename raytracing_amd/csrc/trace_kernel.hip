@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     float4* const             rayrec = wave_lds;
     float* const              xbuf   = reinterpret_cast<float*>(wave_lds);
     unsigned long long* const res    = reinterpret_cast<unsigned long long*>(wave_lds + 128);
-    uint32_t* const           queue  = reinterpret_cast<uint32_t*>(wave_lds + 160);
+    uint32_t* const           queue  = reinterpret_cast<uint32_t*>(wave_lds + 160);   // 256 entries
 
     // wave-level work reservation: [w_next, w_end) is owned, pf holds the next reservation (lane 0's value)
     uint32_t pf = 0;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
             res[lane] = 0x7F7FFFFFFFFFFFFFull;         // (FLT_MAX, kNoHit): raytracer.cpp:251
             auto run_batch = [&](uint32_t nb) {
                 if (lane < nb) {
-                    const uint32_t ent = queue[(q_head + lane) & 127u];
+                    const uint32_t ent = queue[(q_head + lane) & 255u];
                     const uint32_t ray = ent >> 26;
                     uint32_t       i   = ent & 0x03FFFFFFu;
                     if (FILTER == kFilterMfma) {       // decode (group, s, bit) -- see the extraction below
@@ -301,13 +301,29 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 q_count -= nb;
                 c_cand += nb;
             };
+            // the ring holds 256 entries: at most 63 are pending after the drain, one call adds at most 128
             auto enqueue = [&](bool has, uint32_t entry) {
                 const uint64_t m = __ballot(has);
                 if (m) {
-                    if (q_count >= 64u) run_batch(64u);           // keeps q_count + 64 <= 128
-                    if (has) queue[(q_head + q_count + rank_in(m)) & 127u] = (lane << 26) | entry;
+                    while (q_count >= 64u) run_batch(64u);
+                    if (has) queue[(q_head + q_count + rank_in(m)) & 255u] = (lane << 26) | entry;
                     q_count += (uint32_t)__popcll(m);
                 }
+            };
+            // the lowest AND the highest set bit of a sign word in one step (most non-empty words hold one or two
+            // candidates); returns the word without them
+            auto enqueue2 = [&](uint32_t wv, uint32_t code) -> uint32_t {
+                const uint32_t w2 = wv & (wv - 1u);
+                const uint64_t m1 = __ballot(wv != 0u);
+                if (!m1) return 0u;
+                const uint64_t m2 = __ballot(w2 != 0u);
+                while (q_count >= 64u) run_batch(64u);
+                const uint32_t tail = q_head + q_count, n1 = (uint32_t)__popcll(m1);
+                const uint32_t lz   = (uint32_t)__builtin_clz(w2 | 1u);
+                if (wv != 0u) queue[(tail + rank_in(m1)) & 255u] = (lane << 26) | code | (uint32_t)__builtin_ctz(wv | 0x80000000u);
+                if (w2 != 0u) queue[(tail + n1 + rank_in(m2)) & 255u] = (lane << 26) | code | (31u - lz);
+                q_count += n1 + (uint32_t)__popcll(m2);
+                return w2 & ~(0x80000000u >> lz);
             };
 
             if (FILTER == kFilterValu) {
@@ -409,14 +425,10 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     // A queue entry is the code (group << 7) | (s << 5) | bit, decoded in run_batch: word s = 2 w + hf'
                     // came from lane half hf' and tiles 2 w, 2 w + 1 of this 128-sphere group; its bit b (from the LSB) was
                     // pushed p = 31 - b th: tile 2 w + (p >> 4), v = p & 15, sphere row 8 (v >> 2) + 4 hf' + (v & 3).
-                    // First the lowest candidate of each word; then the rare leftovers, one per lane and round.
+                    // First the lowest and the highest candidate of each word; then the rare leftovers, one per lane and round.
                     const uint32_t grp_code = (base >> 7) << 7;
 #pragma unroll
-                    for (uint32_t s = 0; s < 4u; ++s) {
-                        const uint32_t wv = word[s];
-                        enqueue(wv != 0u, (grp_code | (s << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
-                        word[s] = wv & (wv - 1u);
-                    }
+                    for (uint32_t s = 0; s < 4u; ++s) word[s] = enqueue2(word[s], grp_code | (s << 5));
                     while (__ballot((word[0] | word[1] | word[2] | word[3]) != 0)) {
                         const bool     n0 = word[0] != 0u, n1 = word[1] != 0u, n2 = word[2] != 0u;
                         const uint32_t sl = n0 ? 0u : (n1 ? 1u : (n2 ? 2u : 3u));
@@ -486,19 +498,57 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
         }
 
         RTX_STAMP(4);
-        // randomInUnitSphere (utils.cu:74-83) for the diffuse and metal lanes: try t from block t of event bounce+1
-        V3 rnd = mk(0, 0, 0);
+        // randomInUnitSphere (utils.cu:74-83) for the diffuse and metal lanes -- try t comes from block t of event
+        // bounce + 1 -- and the glass lanes' single draw (block 0, word 0), generated COOPERATIVELY: rejection sampling
+        // in lockstep would run as many rounds as the unluckiest lane needs tries (5-6 for ~30 lanes at 52 % acceptance)
+        // with most lanes idle.  Instead, each round the p pending lanes publish (pixel, sample, slot base, next try) and
+        // all 64 lanes work for them: lane i draws try t_j + i / p for pending lane number j = i % p.  An owner takes its
+        // lowest accepted try, the same point the sequential loop returns (try 20 is always accepted, utils.cu:80).
+        V3    rnd = mk(0, 0, 0);
+        float glass_u = 0.0f;
+#ifdef RTX_EXP_DOUBLE_RNG
+        for (int rep_ = 0; rep_ < 2; ++rep_)
+#endif
         {
-            bool     pending = hit && (mtype == RTX_MATERIAL_DIFFUSE || mtype == RTX_MATERIAL_METAL);
-            uint32_t t = 0;
-            while (__ballot(pending)) {
-                float bb[4];
-                rng_block(P, pix, s_cur, bounce + 1u, t, bb);
+            const bool is_glass = hit && mtype == RTX_MATERIAL_GLASS;
+            bool       pending  = hit && (mtype == RTX_MATERIAL_DIFFUSE || mtype == RTX_MATERIAL_METAL || is_glass);
+            uint32_t   t = 0;
+            uint4* const    own   = reinterpret_cast<uint4*>(wave_lds);               // the ray records are free again
+            float4* const   tries = wave_lds + 64;
+            uint32_t* const kbest = reinterpret_cast<uint32_t*>(wave_lds + 128);      // and so are the result slots
+            for (;;) {
+                const uint64_t m = __ballot(pending);
+                if (!m) break;
+                const uint32_t p    = (uint32_t)__popcll(m);
+                const uint32_t rank = rank_in(m);
                 if (pending) {
-                    rnd = sub(scale(2.0f, mk(bb[0], bb[1], bb[2])), mk(1, 1, 1));
-                    if (!(sqlen(rnd) >= 1.0f && t < 20)) pending = false;
+                    own[rank]   = make_uint4(pix, s_cur, (bounce + 1u) * 32u, t | (is_glass ? 0x100u : 0u));
+                    kbest[rank] = 0xFFu;
                 }
-                t++;
+                const float    rp = __builtin_amdgcn_rcpf((float)p);                     // 1 ulp is plenty: see the margins below
+                const uint32_t k  = (uint32_t)(((float)lane + 0.5f) * rp);             // lane / p (never within 1/128 of an integer)
+                const uint32_t j  = lane - k * p;
+                const uint4    ow = own[j];
+                const uint32_t tt = (ow.w & 0xFFu) + k;
+                const bool     og = (ow.w & 0x100u) != 0u;
+                uint32_t r[4];
+                philox4x32_10(ow.z + tt, ow.y, ow.x, 0u, P.key0, P.key1, r);
+                const float u0 = u32_to_unit(r[0]), u1 = u32_to_unit(r[1]), u2 = u32_to_unit(r[2]);
+                const V3    pt = sub(scale(2.0f, mk(u0, u1, u2)), mk(1, 1, 1));
+                const bool  accept = og ? (k == 0u) : (tt <= 20u && !(sqlen(pt) >= 1.0f && tt < 20u));
+                tries[lane] = make_float4(u0, u1, u2, 0.0f);
+                if (accept) __hip_atomic_fetch_min(&kbest[j], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pending) {
+                    const uint32_t kb = kbest[rank];
+                    if (kb != 0xFFu) {
+                        const float4 w = tries[kb * p + rank];
+                        if (is_glass) glass_u = w.x;
+                        else          rnd = sub(scale(2.0f, mk(w.x, w.y, w.z)), mk(1, 1, 1));
+                        pending = false;
+                    } else {
+                        t += (uint32_t)((63.5f - (float)rank) * rp) + 1u;            // tries this lane was given: (63 - rank) / p + 1
+                    }
+                }
             }
         }
 
@@ -546,9 +596,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 } else {
                     prob = 1.0f;
                 }
-                float bb[4];
-                rng_block(P, pix, s_cur, bounce + 1u, 0, bb);
-                nd_ = (bb[0] < prob) ? reflected : refracted;
+                nd_ = (glass_u < prob) ? reflected : refracted;           // material.cu:98-103, the draw made above
             } else {
                 ok = false;   // reference: printf + assert(0), material.cu:34-36; uploads reject such tables
             }
