@@ -54,3 +54,58 @@ def test_far_origins_and_large_offsets(ra, oracle, golden_scenes):
         assert st["filter_misses"] == 0
         o_accum, o_primary, _ = oracle.render(table, ocam, rows, cols, 0, spp, 50, 5, want_primary=True)
         assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+
+
+@pytest.mark.parametrize("factor", [2.0 ** -10, 1024.0, 3.0e4, 1.0e7])
+def test_scene_scale_sweep(ra, oracle, golden_scenes, factor):
+    """The MFMA filter works on f16 operands behind a per-scene power-of-two scale: the same scene at very different
+    sizes must keep zero filter misses and the oracle's bits."""
+    table = golden_scenes["book1"].copy()
+    f = np.float32(factor)
+    table[:, 0:4] *= f                                   # centres and radii
+    cols, rows, spp = 120, 80, 2
+    pos, look = np.array([13, 2, 3], dtype=np.float32) * f, np.zeros(3, dtype=np.float32)
+    args = (20.0, np.float32(cols) / np.float32(rows), np.float32(0.1) * f, np.float32(10.0) * f, pos, (0, 1, 0), look)
+    cam, ocam = ra.Camera(*args), oracle.camera(*args)
+    ctx = ra.Context(0)
+    try:
+        ctx.set_filter(ra.FILTER_MFMA)
+        ctx.upload_scene(table)
+        ctx.set_camera(cam)
+        primary, st = ctx.render(cols, rows, 0, spp, 50, 5, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+        accum = ctx.read_accum()
+    finally:
+        ctx.close()
+    assert st["filter_misses"] == 0
+    assert st["candidates"] < 0.02 * st["sphere_tests"]
+    o_accum, o_primary, _ = oracle.render(table, ocam, rows, cols, 0, spp, 50, 5, want_primary=True)
+    # at 1e7 a few paths overflow fp32 (|oc|^2 ~ 1e34 times a ~ 1e16) in the reference's own arithmetic: both sides then
+    # hold NaN in the same pixels, with the host's and the GPU's different default NaN bit patterns
+    same = (bits(accum) == bits(o_accum)) | (np.isnan(accum) & np.isnan(o_accum))
+    assert (primary == o_primary).all() and same.all()
+    assert factor > 1.0e5 or not np.isnan(accum).any()
+
+
+def test_camera_outside_f16_range_uses_valu_filter(ra, oracle, golden_scenes):
+    """A camera far outside the range the scene's scale leaves for ray origins: the launch takes the VALU filter (same
+    candidate count as a VALU context), results unchanged."""
+    table = golden_scenes["book1"]
+    cols, rows, spp = 64, 40, 1
+    pos = np.array([4.0e6, 2.0e5, 1.0e6], dtype=np.float32)
+    args = (0.0005, np.float32(cols) / np.float32(rows), 0.0, 10.0, pos, (0, 1, 0), (0, 0, 0))
+    out = {}
+    for kind in (ra.FILTER_VALU, ra.FILTER_MFMA):
+        ctx = ra.Context(0)
+        try:
+            ctx.set_filter(kind)
+            ctx.upload_scene(table)
+            ctx.set_camera(ra.Camera(*args))
+            primary, st = ctx.render(cols, rows, 0, spp, 50, 5, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+            out[kind] = (primary, ctx.read_accum(), st)
+        finally:
+            ctx.close()
+    (p0, a0, s0), (p1, a1, s1) = out[ra.FILTER_VALU], out[ra.FILTER_MFMA]
+    assert s0["filter_misses"] == 0 and s1["filter_misses"] == 0
+    assert s0["candidates"] == s1["candidates"]
+    o_accum, o_primary, _ = oracle.render(table, oracle.camera(*args), rows, cols, 0, spp, 50, 5, want_primary=True)
+    assert (p1 == o_primary).all() and (bits(a1) == bits(o_accum)).all() and (p0 == p1).all()
