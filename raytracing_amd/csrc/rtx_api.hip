@@ -136,11 +136,13 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
             hot[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0e30f);   // padding: never a candidate
         }
     }
-    // MFMA filter: per 32-sphere tile, lane (hf = lane >> 5, r = lane & 31) holds, for sphere 32 t + r, the eight f16
-    // k-slots of components 2 hf and 2 hf + 1: (x1,x1,x2,x2) of the two-way split of scale * cx, cy (hf 0) or of
-    // scale * cz followed by (1, 1, K1, K2), K = scale^2 K'' 2^-15, K'' = |C|^2 - r^2 - margin (hf 1).  `scale` is the
-    // largest power of two that keeps every sphere-side value, every ray origin on a sphere (|o| <= |C| + r) and K
-    // inside the f16 range; the camera origin is checked against the same bound per launch (else the VALU filter runs).
+    // MFMA filter (see trace_kernel.hip): per 32-sphere tile two A operands of 64 lanes x 16 B; lane (hf = lane >> 5,
+    // r = lane & 31) holds, for sphere 32 t + r, the eight f16 k-slots of slot group (m, hf):
+    //   (0,0) CxCx, CyCy, (2^15, 2^15)    (0,1) CzCz, CxCy, (K1, K2)    (1,0) CxCz, CyCz, (Lz1, Lz1)    (1,1) Lx, Ly, (Lz2, 0)
+    // with the quadratic monomials Q = scale^2 C_i C_j 2^-15, the linear ones L_i = 2 scale C_i, K = scale^2 K'' 2^-15,
+    // K'' = |C|^2 - r^2 - margin; a monomial X next to a monomial Y fills (X1,X1 | X2,Y2 | Y1,Y1).  `scale` is the largest
+    // power of two that keeps all of these, and 2 scale (|C| + r) for any bounce origin, inside the f16 range; the camera
+    // origin is checked against the same bound per launch (else the VALU filter runs).
     const uint32_t n_pad_mfma = (n + 127u) & ~127u;
     double max_c = 0.0, max_o = 0.0, max_k = 0.0;
     bool   finite = true;
@@ -156,7 +158,7 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     if (finite && n > 0) {
         while (exp2 > -40) {
             const double sgm = std::ldexp(1.0, exp2);
-            if (sgm * max_c <= 60000.0 && 2.0 * sgm * max_o <= 60000.0 && sgm * sgm * max_k * std::ldexp(1.0, -15) + std::ldexp(1.0, -9) <= 60000.0) break;
+            if (2.0 * sgm * max_c <= 60000.0 && 2.0 * sgm * max_o <= 60000.0 && sgm * sgm * max_k * std::ldexp(1.0, -15) + 1.0 <= 60000.0) break;
             --exp2;
         }
     } else {
@@ -164,30 +166,41 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     }
     const bool   mfma_ok = finite && exp2 > -40;
     const double sgm = std::ldexp(1.0, mfma_ok ? exp2 : 0);
-    std::vector<uint4> tabA(((size_t)n_pad_mfma + 32u) * 2u);      // + one spare tile: the kernel prefetches one tile ahead
+    std::vector<uint4> tabA(((size_t)n_pad_mfma + 32u) * 4u);      // + one spare tile: the kernel prefetches one tile ahead
     auto split2 = [](double x) -> uint32_t {                        // (x1 | x2 << 16), round to nearest
         const _Float16 x1 = (_Float16)x;
         const _Float16 x2 = (_Float16)(x - (double)x1);
         uint16_t a, b; memcpy(&a, &x1, 2); memcpy(&b, &x2, 2);
         return (uint32_t)a | ((uint32_t)b << 16);
     };
-    auto dup = [](uint32_t lohi, int which) -> uint32_t { const uint32_t h = which ? (lohi >> 16) : (lohi & 0xFFFFu); return h | (h << 16); };
+    // A-side dwords of a slot group holding monomials X, Y and two extra slots
+    auto group = [](uint32_t X, uint32_t Y, uint32_t extra) -> uint4 {
+        const uint32_t x1 = X & 0xFFFFu, x2 = X >> 16, y1 = Y & 0xFFFFu, y2 = Y >> 16;
+        return make_uint4(x1 | (x1 << 16), x2 | (y2 << 16), y1 | (y1 << 16), extra);
+    };
+    const double q = sgm * sgm * std::ldexp(1.0, -15);
     for (uint32_t i = 0; i < n_pad_mfma + 32u; ++i) {
-        uint32_t px = 0, py = 0, pz = 0, pk;
+        uint32_t pxx = 0, pyy = 0, pzz = 0, pxy = 0, pxz = 0, pyz = 0, plx = 0, ply = 0, plz = 0, pk, pone = 0;
         if (i < n && mfma_ok) {
-            const double C2 = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
+            const double X = cx[i], Y = cy[i], Z = cz[i];
+            const double C2 = X * X + Y * Y + Z * Z;
             const double r2 = (double)radius[i] * radius[i];
             const double Kp = C2 - r2;
-            const double Kpp = Kp - kGammaSphere * (C2 + r2 + std::fabs(Kp)) - std::ldexp(1.0, -9) / (sgm * sgm);
-            px = split2(sgm * cx[i]); py = split2(sgm * cy[i]); pz = split2(sgm * cz[i]);
-            pk = split2(sgm * sgm * Kpp * std::ldexp(1.0, -15));
+            const double Kpp = Kp - kGammaSphere * (C2 + r2 + std::fabs(Kp)) - kMfmaAbsMargin / (sgm * sgm);
+            pxx = split2(q * X * X); pyy = split2(q * Y * Y); pzz = split2(q * Z * Z);
+            pxy = split2(q * X * Y); pxz = split2(q * X * Z); pyz = split2(q * Y * Z);
+            plx = split2(2.0 * sgm * X); ply = split2(2.0 * sgm * Y); plz = split2(2.0 * sgm * Z);
+            pk  = split2(q * Kpp);
+            pone = 0x78007800u;                                      // (2^15, 2^15): carries the per-ray constant
         } else {
-            pk = split2(60000.0);                                    // padding: c = 60000 * 2^15 + ..., never negative
+            pk = split2(60000.0);                                    // padding: w = 60000 * 2^15, never negative
         }
         const uint32_t t = i >> 5, r = i & 31u;
-        const uint32_t ONE2 = 0x3C003C00u;                           // (1.0, 1.0): carries the ray's -scale o.d' into the h form
-        tabA[(size_t)t * 64u + r]       = make_uint4(dup(px, 0), dup(px, 1), dup(py, 0), dup(py, 1));
-        tabA[(size_t)t * 64u + 32u + r] = make_uint4(dup(pz, 0), dup(pz, 1), ONE2, pk);
+        const uint32_t lz1 = plz & 0xFFFFu, lz2 = plz >> 16;
+        tabA[((size_t)2u * t) * 64u + r]            = group(pxx, pyy, pone);
+        tabA[((size_t)2u * t) * 64u + 32u + r]      = group(pzz, pxy, pk);
+        tabA[((size_t)2u * t + 1u) * 64u + r]       = group(pxz, pyz, lz1 | (lz1 << 16));
+        tabA[((size_t)2u * t + 1u) * 64u + 32u + r] = group(plx, ply, lz2);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->hot_mfma) (void)hipFree(c->hot_mfma);
@@ -283,8 +296,18 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         if (!fits) filter = kFilterValu;
     }
     const bool   lds_table = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
-    uint32_t block = 256u;
+    // workgroup size: the one that keeps the most waves resident per SIMD (the LDS-resident table is per workgroup, so a
+    // larger group amortises it over more waves); RTX_BLOCK overrides
+    uint32_t block = 0u;
     if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) block = (uint32_t)v; }
+    if (!block) {
+        uint32_t best_waves = 0;
+        for (uint32_t cand : { 512u, 256u }) {
+            const size_t lb = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, cand);
+            const uint32_t waves = (uint32_t)trace_occupancy(filter, lds_table, lb, cand) * (cand / 64u);
+            if (waves > best_waves) { best_waves = waves; block = cand; }
+        }
+    }
     size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, block);
     if (const char* pad = getenv("RTX_LDS_PAD")) lds_bytes += (size_t)atoi(pad);      // tuning aid: lowers the occupancy
     const int    occ       = trace_occupancy(filter, lds_table, lds_bytes, block);

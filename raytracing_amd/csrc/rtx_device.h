@@ -17,24 +17,27 @@ constexpr uint32_t kMaxBlock   = 512;                  // threads per workgroup 
 constexpr uint32_t kWaveBatch  = 256;                  // work items a wave reserves per trip to the global counter
 constexpr uint32_t kWaveLdsBytes = 3584;               // per wave: 64 ray records (2 KB), 64 result slots (512 B), 256 queue entries (1 KB)
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
-// MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) + 2^-9 / scale^2 per sphere and gamma * |o|^2 per ray,
-// gamma = 2^-16 = 256 ulp (ulp = 2^-24).  Budget, in ulp of (|C|^2 + |o|^2): the two-way f16 split leaves 2^-22 per
-// operand, i.e. 8 ulp per product; with d' itself (4), -o.d' (4) and the accumulation of v_mfma_f32_32x32x16_f16
-// (<= 5.7 ulp of sum |terms|, tools/microbench/mfma_f16_error.hip) h is off by <= 24 ulp (|C| + |o|), h^2 by <= 96;
-// the c form adds 8 (split of -2 o.C) + 4 (K'') + 17 (accumulation on top of |o|^2 - h^2); the reference's own rounding
-// of b*b - a*c moves the sign within 34 ulp.  Sum 159 of 256.  The 2^-9 / scale^2 term covers f16 subnormals (x2 parts
-// below 2^-14 are rounded to multiples of 2^-24; the largest effect is K2 against the ray side's 2^15).
+// MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) + kMfmaAbsMargin / scale^2 per sphere and gamma * |o|^2 per
+// ray, gamma = 2^-16 = 256 ulp (ulp = 2^-24).  Budget, in ulp of (|C|^2 + |o|^2), for the single quadratic form: a monomial
+// is x1 p1 + x1 p2 + x2 p1 with both factors split to 2^-22, i.e. 12 ulp of |monomial x coefficient|; the coefficients
+// themselves (d'_i d'_j, o.d' d'_i - o_i, |o|^2 - (o.d')^2) carry <= 5 ulp from d' and o.d'.  Quadratic part: 17 ulp of
+// (sum |C_i d'_i|)^2 <= 17 |C|^2; linear part: 17 ulp of 4 |C||o| <= 34; K'' 4; constant 8 |o|^2; accumulation of the two
+// chained v_mfma_f32_32x32x16_f16 (<= 5.7 ulp of sum |terms| each, tools/microbench/mfma_f16_error.hip, sum |terms| <=
+// 4 (|C|^2 + |o|^2)) 46; the reference's own rounding of b*b - a*c moves the sign within 34.  Sum 143 of 256.
+// kMfmaAbsMargin covers f16 subnormals: second parts below 2^-14 are rounded to multiples of 2^-24, which against a
+// partner of up to 2^16 is 2^-9 (in scale^2 units) per slot pair; ten monomials.
+constexpr double   kMfmaAbsMargin = 0.03125;                         // 2^-5
 constexpr float    kGammaRay   = 1.52587890625e-05f * 1.0625f;   // 2^-16 plus room for the rounding of |o|^2 itself
 constexpr double   kGammaSphere = 1.52587890625e-05;
 enum FilterKind { kFilterValu = 0, kFilterMfma = 1 };
 constexpr uint32_t kMaxLdsSpheres = 2048;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
-constexpr uint32_t kMaxLdsSpheresMfma = 1024;          // MFMA filter: 32 B/sphere (+ 16 B exact record)
+constexpr uint32_t kMaxLdsSpheresMfma = 1024;          // MFMA filter: 64 B/sphere (+ 16 B exact record)
 
 enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStFilterMiss, kStCount };
 
 struct TraceParams {
     const float4* hot;      // n_pad x (cx, cy, cz, -(r^2 (1+eps)))  -- the VALU filter's view of a sphere
-    const float4* hot_mfma; // (n_pad_mfma/32 + 1) tiles x 64 lanes x 16 B: f16 A operands (cx, cy, cz, K'') of the MFMA filter
+    const float4* hot_mfma; // (n_pad_mfma/32 + 1) tiles x 2 MFMAs x 64 lanes x 16 B: f16 A operands (ten monomials per sphere) of the MFMA filter
     uint32_t      n_pad_mfma;
     float         mfma_scale; // power of two applied to the sphere side of the MFMA filter (f16 range)
     const float4* exact;    // n x (cx, cy, cz, r)                   -- sphere.h:24-28 geometry, as uploaded

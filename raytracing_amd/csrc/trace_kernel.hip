@@ -129,9 +129,9 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     // (1) stage the filter's sphere table into LDS once per workgroup (16 B per sphere for the VALU filter,
-    //     32 B per sphere -- the f16 A operands of 32-sphere tiles, plus one spare tile -- for the MFMA filter)
+    //     64 B per sphere -- the f16 A operands of 32-sphere tiles, two MFMAs each, plus one spare tile -- for the MFMA filter)
     const float4* table = (FILTER == kFilterMfma) ? P.hot_mfma : P.hot;
-    const uint32_t table_f4 = (FILTER == kFilterMfma) ? (P.n_pad_mfma + 32u) * 2u : P.n_pad;
+    const uint32_t table_f4 = (FILTER == kFilterMfma) ? (P.n_pad_mfma + 32u) * 4u : P.n_pad;
     float4* wave_lds;
     const float4* exact = P.exact;
     if (LDS_TABLE) {
@@ -350,46 +350,58 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     }
                 }
             } else {
-                // ---- MFMA filter: v_mfma_f32_32x32x16_f16 on two-way f16 splits (x = x1 + x2, 22 bits).  A tile is 32
-                // spheres x 32 rays with K = 16 = 4 components (cx, cy, cz, K''/-o.d') x the 4 partial products
-                // x1 p1, x1 p2, x2 p1, x2 p2.  Lane (hf = lane >> 5, c = lane & 31) feeds k-slots 8 hf .. 8 hf + 7
-                // (components 2 hf, 2 hf + 1) of ray c (first MFMA) and ray 32 + c (second MFMA), and receives, for each
-                // of the two rays, the results of spheres 8 b + 4 hf + j (v = 4 b + j) of the tile.  The sphere side is
-                // pre-scaled by sg = P.mfma_scale (a power of two that puts the scene into f16 range), so the h form
-                // yields sg h and everything after it carries sg^2.  Each ray's owner first publishes its quantities.
+                // ---- MFMA filter.  The inflated discriminant test is ONE quadratic form in the sphere,
+                //   w = K'' + (|o|^2' - (o.d')^2) + sum_i 2 C_i (o.d' d'_i - o_i) - sum_i C_i^2 d'_i^2 - 2 sum_{i<j} C_i C_j d'_i d'_j
+                // (= |oc|^2 - r^2 - (oc.d')^2 minus the margins), i.e. a dot product of ten per-sphere monomials
+                // (C_i C_j, C_i, 1) with ten per-ray coefficients: K = 32 = two v_mfma_f32_32x32x16_f16 per 32 spheres x 32
+                // rays, and nothing but the sign capture is left for the VALU.  Every factor is split into two f16 parts
+                // (x = x1 + x2 + e, |e| <= 2^-22 |x|) and a monomial takes three k-slots, x1 p1 + x1 p2 + x2 p1; K'' (against the
+                // exact 2^15) and the per-ray constant (against the sphere side's 2^15) take two.  The sphere side is
+                // pre-scaled (sg = P.mfma_scale, a power of two, and 2^-15 on the quadratic monomials) so that everything
+                // stays inside the f16 range.  Lane (hf = lane >> 5, c = lane & 31) feeds k-slots 8 hf .. 8 hf + 7 of both
+                // MFMAs for ray c (first pair) and ray 32 + c (second pair) and receives, for each of the two rays, the
+                // results of spheres 8 b + 4 hf + j (v = 4 b + j) of the tile.  Slot groups (MFMA m, half hf):
+                //   (0,0) CxCx, CyCy, const    (0,1) CzCz, CxCy, K''    (1,0) CxCz, CyCz, Cz[x1p1, x1p2]    (1,1) Cx, Cy, Cz[x2p1]
+                // Each ray's owner first publishes (d', o.d', o, |o|^2') for the lanes that build its operands.
                 const float rs = __builtin_amdgcn_rsqf(a);
                 const float fx = d.x * rs, fy = d.y * rs, fz = d.z * rs;
                 const float od = __builtin_fmaf(o.z, fz, __builtin_fmaf(o.y, fy, o.x * fx));
                 const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
-                const float sg = P.mfma_scale, m2s = -2.0f * sg;
                 float4* const xbuf4 = reinterpret_cast<float4*>(xbuf);
-                xbuf4[lane * 2u]      = make_float4(fx, fy, m2s * o.x, m2s * o.y);
-                xbuf4[lane * 2u + 1u] = make_float4(fz, -sg * od, m2s * o.z, (sg * sg) * (oo - kGammaRay * oo));   // |o|^2 minus the ray's share of the margin
+                xbuf4[lane * 2u]      = make_float4(fx, fy, fz, od);
+                xbuf4[lane * 2u + 1u] = make_float4(o.x, o.y, o.z, oo - kGammaRay * oo);      // |o|^2 minus the ray's share of the margin
                 const uint32_t hf = lane >> 5, cl = lane & 31u;
-                h8v   bh[2], bc[2];
-                float ooa[2];
+                const float    sg = P.mfma_scale, T = 32768.0f;
+                h8v b0[2], b1[2];
 #pragma unroll
                 for (uint32_t half = 0; half < 2u; ++half) {
                     const uint32_t ray = half * 32u + cl;
-                    const float4   v   = xbuf4[ray * 2u + hf];
-                    ooa[half]          = xbuf[ray * 8u + 7u];
-                    const uint32_t pa = split_f16_pair(v.x), pb = split_f16_pair(v.y), pc = split_f16_pair(v.z), pd = split_f16_pair(v.w);
-                    // hf 0: h = (d'x, d'y), c = (-2 sg ox, -2 sg oy).   hf 1: h = (d'z, then -sg o.d' against the sphere
-                    // side's (1, 1, K1, K2)), c = (-2 sg oz, then 2^15 against K1, K2 = sg^2 K'' 2^-15)
-                    uint4 H, C;
-                    H.x = pa; H.y = pa; H.z = pb; H.w = hf ? 0u : pb;
-                    C.x = pc; C.y = pc; C.z = hf ? 0u : pd; C.w = hf ? 0x78007800u : pd;
-                    bh[half] = __builtin_bit_cast(h8v, H);
-                    bc[half] = __builtin_bit_cast(h8v, C);
+                    const float4   dv = xbuf4[ray * 2u], ov = xbuf4[ray * 2u + 1u];
+                    const float    gz = sg * __builtin_fmaf(dv.w, dv.z, -ov.z);             // sg (o.d' d'_z - o_z), against 2 sg C_z
+                    // first MFMA: hf 0: -2^15 d'x^2, -2^15 d'y^2, constant sg^2 2^-15 (|o|^2' - (o.d')^2);  hf 1: -2^15 d'z^2, -2^16 d'x d'y, 2^15
+                    const float x0 = -T * (hf ? dv.z * dv.z : dv.x * dv.x);
+                    const float y0 = -T * (hf ? 2.0f * (dv.x * dv.y) : dv.y * dv.y);
+                    const float e0 = (sg * sg * (1.0f / 32768.0f)) * __builtin_fmaf(-dv.w, dv.w, ov.w);
+                    // second MFMA: hf 0: -2^16 d'x d'z, -2^16 d'y d'z, g_z (x1p1, x1p2);  hf 1: g_x, g_y, g_z (x2p1)
+                    const float x1 = hf ? sg * __builtin_fmaf(dv.w, dv.x, -ov.x) : (-2.0f * T) * (dv.x * dv.z);
+                    const float y1 = hf ? sg * __builtin_fmaf(dv.w, dv.y, -ov.y) : (-2.0f * T) * (dv.y * dv.z);
+                    const uint32_t px0 = split_f16_pair(x0), py0 = split_f16_pair(y0), pe0 = split_f16_pair(e0);
+                    const uint32_t px1 = split_f16_pair(x1), py1 = split_f16_pair(y1), pgz = split_f16_pair(gz);
+                    // a monomial's slots are (p1, p2 | p1, ...): dwords (X.p1, X.p2), (X.p1, Y.p1), (Y.p1, Y.p2), extra
+                    uint4 B0, B1;
+                    B0.x = px0; B0.y = (px0 & 0xFFFFu) | (py0 << 16); B0.z = py0; B0.w = hf ? 0x78007800u : pe0;
+                    B1.x = px1; B1.y = (px1 & 0xFFFFu) | (py1 << 16); B1.z = py1; B1.w = hf ? (pgz & 0xFFFFu) : pgz;
+                    b0[half] = __builtin_bit_cast(h8v, B0);
+                    b1[half] = __builtin_bit_cast(h8v, B1);
                 }
-                const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t: tabA[t * 64]
+                const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t, MFMA m: tabA[(2 t + m) * 64]
                 // the operands are in registers: the same 2 KB now take the ray records of the exact re-test (a wave's
                 // LDS accesses complete in order)
                 rayrec[lane * 2u]      = make_float4(o.x, o.y, o.z, a);
                 rayrec[lane * 2u + 1u] = make_float4(d.x, d.y, d.z, 0.0f);
 
                 RTX_STAMP(8);
-                h8v A_next = __builtin_bit_cast(h8v, tabA[0]);
+                h8v A0_next = __builtin_bit_cast(h8v, tabA[0]), A1_next = __builtin_bit_cast(h8v, tabA[64]);
                 for (uint32_t base = 0; base < P.n_pad_mfma; base += 128u) {
                     uint32_t word[4];
 #pragma unroll
@@ -397,17 +409,15 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                         uint32_t m0 = 0u, m1 = 0u;
 #pragma unroll
                         for (uint32_t tt = 0; tt < 2u; ++tt) {
-                            const h8v A = A_next;
-                            A_next = __builtin_bit_cast(h8v, tabA[((base >> 5) + 2u * w + tt + 1u) * 64u]);   // the table ends with a spare tile
+                            const h8v A0 = A0_next, A1 = A1_next;
+                            const uint32_t nt = (base >> 5) + 2u * w + tt + 1u;           // the table ends with a spare tile
+                            A0_next = __builtin_bit_cast(h8v, tabA[(2u * nt) * 64u]);
+                            A1_next = __builtin_bit_cast(h8v, tabA[(2u * nt + 1u) * 64u]);
                             const f16v zero = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-                            f16v h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bh[0], zero, 0, 0, 0);
-                            f16v h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bh[1], zero, 0, 0, 0);
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) h0[j] = __builtin_fmaf(-h0[j], h0[j], ooa[0]);
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) h1[j] = __builtin_fmaf(-h1[j], h1[j], ooa[1]);
-                            h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bc[0], h0, 0, 0, 0);
-                            h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bc[1], h1, 0, 0, 0);
+                            f16v h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0[0], zero, 0, 0, 0);
+                            f16v h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0[1], zero, 0, 0, 0);
+                            h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, b1[0], h0, 0, 0, 0);
+                            h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, b1[1], h1, 0, 0, 0);
 #pragma unroll
                             for (int j = 0; j < 16; ++j) m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(h0[j]), 31u);
 #pragma unroll
@@ -731,7 +741,7 @@ static const void* select_kernel(int filter, bool lds_table, bool validate)
 
 size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block)
 {
-    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 32 : (size_t)n_pad * 16) : 0;
+    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 64 : (size_t)n_pad * 16) : 0;
     const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
     return table + exact + (size_t)(block / 64) * kWaveLdsBytes;
 }
