@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     float* const              xbuf   = reinterpret_cast<float*>(wave_lds);
     unsigned long long* const res    = reinterpret_cast<unsigned long long*>(wave_lds + 128);
     uint32_t* const           queue  = reinterpret_cast<uint32_t*>(wave_lds + 160);   // 256 entries
+    uint2* const              wordq  = reinterpret_cast<uint2*>(wave_lds + 224);      // 128 entries (MFMA filter)
 
     // wave-level work reservation: [w_next, w_end) is owned, pf holds the next reservation (lane 0's value)
     uint32_t pf = 0;
@@ -301,29 +302,36 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 q_count -= nb;
                 c_cand += nb;
             };
-            // the ring holds 256 entries: at most 63 are pending after the drain, one call adds at most 128
+            // the ring holds 256 entries: at most 63 are pending after the drain, one call adds at most 64
             auto enqueue = [&](bool has, uint32_t entry) {
                 const uint64_t m = __ballot(has);
                 if (m) {
                     while (q_count >= 64u) run_batch(64u);
-                    if (has) queue[(q_head + q_count + rank_in(m)) & 255u] = (lane << 26) | entry;
+                    if (has) queue[(q_head + q_count + rank_in(m)) & 255u] = entry;
                     q_count += (uint32_t)__popcll(m);
                 }
             };
-            // the lowest AND the highest set bit of a sign word in one step (most non-empty words hold one or two
-            // candidates); returns the word without them
-            auto enqueue2 = [&](uint32_t wv, uint32_t code) -> uint32_t {
-                const uint32_t w2 = wv & (wv - 1u);
-                const uint64_t m1 = __ballot(wv != 0u);
-                if (!m1) return 0u;
-                const uint64_t m2 = __ballot(w2 != 0u);
-                while (q_count >= 64u) run_batch(64u);
-                const uint32_t tail = q_head + q_count, n1 = (uint32_t)__popcll(m1);
-                const uint32_t lz   = (uint32_t)__builtin_clz(w2 | 1u);
-                if (wv != 0u) queue[(tail + rank_in(m1)) & 255u] = (lane << 26) | code | (uint32_t)__builtin_ctz(wv | 0x80000000u);
-                if (w2 != 0u) queue[(tail + n1 + rank_in(m2)) & 255u] = (lane << 26) | code | (31u - lz);
-                q_count += n1 + (uint32_t)__popcll(m2);
-                return w2 & ~(0x80000000u >> lz);
+            // MFMA filter: sign words are sparse (one in eight is non-zero), so they are compacted first: non-zero words
+            // go, with their owner and position code, through a second wave-wide ring, and whenever 64 are pending every
+            // lane takes one and peels its bits into the candidate queue.
+            uint32_t wq_head = 0, wq_count = 0;        // wave-uniform
+            auto drain_words = [&](uint32_t nb) {
+                uint32_t w = 0u, code = 0u;
+                if (lane < nb) { const uint2 e = wordq[(wq_head + lane) & 127u]; w = e.x; code = e.y; }
+                wq_head += nb;
+                wq_count -= nb;
+                while (__ballot(w != 0u)) {
+                    enqueue(w != 0u, code | (uint32_t)__builtin_ctz(w | 0x80000000u));
+                    w &= w - 1u;
+                }
+            };
+            auto push_word = [&](uint32_t wv, uint32_t code) {
+                const uint64_t m = __ballot(wv != 0u);
+                if (m) {
+                    if (wq_count >= 64u) drain_words(64u);
+                    if (wv != 0u) wordq[(wq_head + wq_count + rank_in(m)) & 127u] = make_uint2(wv, (lane << 26) | code);
+                    wq_count += (uint32_t)__popcll(m);
+                }
             };
 
             if (FILTER == kFilterValu) {
@@ -345,7 +353,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     if (!tracing) m = 0;
                     while (__ballot(m != 0)) {
                         const uint32_t j = (uint32_t)__clz((int)(m | 1u));
-                        enqueue(m != 0, base + j);
+                        enqueue(m != 0, (lane << 26) | (base + j));
                         m &= ~(0x80000000u >> j);
                     }
                 }
@@ -435,25 +443,14 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     // A queue entry is the code (group << 7) | (s << 5) | bit, decoded in run_batch: word s = 2 w + hf'
                     // came from lane half hf' and tiles 2 w, 2 w + 1 of this 128-sphere group; its bit b (from the LSB) was
                     // pushed p = 31 - b th: tile 2 w + (p >> 4), v = p & 15, sphere row 8 (v >> 2) + 4 hf' + (v & 3).
-                    // First the lowest and the highest candidate of each word; then the rare leftovers, one per lane and round.
                     const uint32_t grp_code = (base >> 7) << 7;
 #pragma unroll
-                    for (uint32_t s = 0; s < 4u; ++s) word[s] = enqueue2(word[s], grp_code | (s << 5));
-                    while (__ballot((word[0] | word[1] | word[2] | word[3]) != 0)) {
-                        const bool     n0 = word[0] != 0u, n1 = word[1] != 0u, n2 = word[2] != 0u;
-                        const uint32_t sl = n0 ? 0u : (n1 ? 1u : (n2 ? 2u : 3u));
-                        const uint32_t wv = n0 ? word[0] : (n1 ? word[1] : (n2 ? word[2] : word[3]));
-                        enqueue(wv != 0u, (grp_code | (sl << 5)) | (uint32_t)__builtin_ctz(wv | 0x80000000u));
-                        const uint32_t cl = wv & (wv - 1u);
-                        word[0] = n0 ? cl : word[0];
-                        word[1] = (!n0 && n1) ? cl : word[1];
-                        word[2] = (!n0 && !n1 && n2) ? cl : word[2];
-                        word[3] = (!n0 && !n1 && !n2) ? cl : word[3];
-                    }
+                    for (uint32_t s = 0; s < 4u; ++s) push_word(word[s], grp_code | (s << 5));
                     RTX_STAMP(9);
                 }
             }
             RTX_STAMP(2);
+            while (wq_count) drain_words(wq_count < 64u ? wq_count : 64u);
             while (q_count) run_batch(q_count < 64u ? q_count : 64u);
             {
                 const unsigned long long rr = res[lane];
