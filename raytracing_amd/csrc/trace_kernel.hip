@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
     if (lane == 0) pf = atomicAdd(P.work_counter, kWaveBatch);
 
     // per-lane path state
-    uint32_t st = kNeedItem, item = 0, pix = 0, s_cur = 0, s_end = 0, bounce = 0;
+    uint32_t st = kNeedItem, item = 0, pix = 0, prow = 0, s_cur = 0, s_end = 0, bounce = 0;
     V3       o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1), acc = mk(0, 0, 0);
     // wave-level counters
     uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0, c_filter_miss = 0, c_cand = 0;
@@ -201,6 +201,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     item           = it;
                     uint32_t chunk = it / P.npix;
                     pix            = it - chunk * P.npix;
+                    prow           = pix / P.cols;                     // once per item, not per sample
                     s_cur          = P.spp_begin + chunk * P.chunk_spp;
                     uint32_t e     = s_cur + P.chunk_spp, lim = P.spp_begin + P.spp_count;
                     s_end          = e < lim ? e : lim;
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
         // ---- (B) camera rays for lanes starting a sample: raytracer.cpp:177-179 + camera.h:75-86 ------------------
         if (__ballot(st == kNeedSample)) {
             const bool go = (st == kNeedSample);
-            uint32_t   px = pix % P.cols, py = pix / P.cols;
+            const uint32_t px = pix - prow * P.cols, py = prow;
             float      b[4];
             rng_block(P, pix, s_cur, 0, 0, b);
             float u = (float)((float)px + b[0]) / (float)P.cols;
@@ -560,6 +561,10 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
         }
 
         RTX_STAMP(5);
+        // |d| and d / |d| once per ray: the metal and glass branches and the background all use them (material.cu:60,
+        // :83-88, :120; raytracer.cpp:278), and in lockstep every branch that any lane takes is paid for by all
+        const float dlen = sqrtf(a);                                       // a = d.d in the order of vector_cuda.h:41
+        const V3    dun  = mk(d.x / dlen, d.y / dlen, d.z / dlen);         // vector_cuda.h:45-59
         if (hit) {
             V3   att = albedo, nd_ = d;
             bool ok  = true;
@@ -567,7 +572,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 V3 target = add(add(hp, hn), rnd);
                 nd_       = sub(target, hp);
             } else if (mtype == RTX_MATERIAL_METAL) {                      // material.cu:58-65
-                V3 vn        = normalized(d);
+                V3 vn        = dun;
                 V3 reflected = sub(vn, scale(2 * dot(vn, hn), hn));
                 nd_          = add(reflected, scale(blur, rnd));
                 ok           = dot(nd_, hn) > 0;
@@ -579,14 +584,14 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 if (dot(d, hn) > 0) {
                     outward = neg(hn);
                     ni      = ior;
-                    cosine  = ior * dot(d, hn) / len(d);
+                    cosine  = ior * dot(d, hn) / dlen;
                 } else {
                     outward = hn;
                     ni      = 1.0f / ior;
-                    cosine  = -dot(d, hn) / len(d);
+                    cosine  = -dot(d, hn) / dlen;
                 }
                 // _refract, material.cu:118-129
-                V3    uv   = normalized(d);
+                V3    uv   = dun;
                 float dt   = dot(uv, outward);
                 float disc = 1.0f - ni * ni * (1.0f - dt * dt);
                 V3    refracted = mk(0, 0, 0);
@@ -624,7 +629,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                 if (recursive) thr = mk(0, 0, 0);                         // raytracer.cpp:233-235
             }
         } else if (tracing) {                                             // _background, raytracer.cpp:276-282
-            V3    unit = normalized(d);
+            V3    unit = dun;
             float t    = 0.5f * (unit.y + 1.0f);
             V3    bg   = add(scale(1.0f - t, mk(1.0f, 1.0f, 1.0f)), scale(t, mk(0.5f, 0.7f, 1.0f)));
             if (!recursive) thr = mul(thr, bg);
