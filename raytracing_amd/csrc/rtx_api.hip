@@ -179,7 +179,9 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
         return make_uint4(x1 | (x1 << 16), x2 | (y2 << 16), y1 | (y1 << 16), extra);
     };
     const double q = sgm * sgm * std::ldexp(1.0, -15);
-    for (uint32_t i = 0; i < n_pad_mfma + 32u; ++i) {
+    const uint4 pad_row = make_uint4(0u, 0u, 0u, split2(60000.0));   // padding: w = 60000 * 2^15, never negative
+    for (uint32_t r = 0; r < 32u; ++r) tabA[((size_t)2u * (n_pad_mfma >> 5)) * 64u + 32u + r] = pad_row;   // the spare tile
+    for (uint32_t i = 0; i < n_pad_mfma; ++i) {
         uint32_t pxx = 0, pyy = 0, pzz = 0, pxy = 0, pxz = 0, pyz = 0, plx = 0, ply = 0, plz = 0, pk, pone = 0;
         if (i < n && mfma_ok) {
             const double X = cx[i], Y = cy[i], Z = cz[i];
@@ -195,7 +197,10 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
         } else {
             pk = split2(60000.0);                                    // padding: w = 60000 * 2^15, never negative
         }
-        const uint32_t t = i >> 5, r = i & 31u;
+        // sphere i = (group << 7) | (w << 6) | (hf << 5) | (tt << 4) | (b << 2) | j sits in tile 4 group + 2 w + tt at MFMA row
+        // 8 b + 4 hf + j: the (word, bit) position at which the kernel finds its sign then spells i (see trace_kernel.hip)
+        const uint32_t t = ((i >> 7) << 2) | (((i >> 6) & 1u) << 1) | ((i >> 4) & 1u);
+        const uint32_t r = (((i >> 2) & 3u) << 3) | (((i >> 5) & 1u) << 2) | (i & 3u);
         const uint32_t lz1 = plz & 0xFFFFu, lz2 = plz >> 16;
         tabA[((size_t)2u * t) * 64u + r]            = group(pxx, pyy, pone);
         tabA[((size_t)2u * t) * 64u + 32u + r]      = group(pzz, pxy, pk);

@@ -123,7 +123,7 @@ __device__ __forceinline__ uint32_t split_f16_pair(float x)
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int FILTER, bool LDS_TABLE, bool VALIDATE>
-__global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
+__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(4))) trace_kernel(const TraceParams P)   // <= 128 VGPRs
 {
     extern __shared__ float4 smem[];
     const uint32_t lane = lane_id();
@@ -279,10 +279,7 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     const uint32_t ent = queue[(q_head + lane) & 255u];
                     const uint32_t ray = ent >> 26;
                     uint32_t       i   = ent & 0x03FFFFFFu;
-                    if (FILTER == kFilterMfma) {       // decode (group, s, bit) -- see the extraction below
-                        const uint32_t pb = 31u - (i & 31u), sl = (i >> 5) & 3u;
-                        i = ((i >> 7) << 7) + ((sl >> 1) << 6) + ((pb >> 4) << 5) + (((pb & 15u) >> 2) << 3) + ((sl & 1u) << 2) + (pb & 3u);
-                    }
+                    if (FILTER == kFilterMfma) i ^= 31u;     // (group, word, bit) -> sphere index, see the extraction below
                     const float4 r0 = rayrec[ray * 2u], r1 = rayrec[ray * 2u + 1u];
                     const float4 s  = exact[i];
                     const V3    ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
@@ -441,9 +438,10 @@ __global__ void __launch_bounds__(kMaxBlock) trace_kernel(const TraceParams P)
                     }
                     RTX_STAMP(2);
                     if (!tracing) { word[0] = 0; word[1] = 0; word[2] = 0; word[3] = 0; }
-                    // A queue entry is the code (group << 7) | (s << 5) | bit, decoded in run_batch: word s = 2 w + hf'
-                    // came from lane half hf' and tiles 2 w, 2 w + 1 of this 128-sphere group; its bit b (from the LSB) was
-                    // pushed p = 31 - b th: tile 2 w + (p >> 4), v = p & 15, sphere row 8 (v >> 2) + 4 hf' + (v & 3).
+                    // A queue entry is (group << 7) | (s << 5) | bit: word s = 2 w + hf' came from lane half hf' and tiles
+                    // 2 w, 2 w + 1 of this 128-sphere group, and its bit b (from the LSB) was pushed p = 31 - b th: tile
+                    // 2 w + (p >> 4), MFMA row 8 ((p >> 2) & 3) + 4 hf' + (p & 3).  The host lays the table out so that
+                    // exactly that row holds sphere (group << 7) | (s << 5) | p, which makes the decode a single xor.
                     const uint32_t grp_code = (base >> 7) << 7;
 #pragma unroll
                     for (uint32_t s = 0; s < 4u; ++s) push_word(word[s], grp_code | (s << 5));
