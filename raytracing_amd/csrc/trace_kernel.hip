@@ -59,11 +59,8 @@ __device__ __forceinline__ V3    normalized(V3 v)                               
 // Philox4x32-10 (Random123 constants).  key = seed, counter = (slot, sample, pixel, 0).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
 {
-#ifndef RTX_EXP_PHILOX_ROUNDS
-#define RTX_EXP_PHILOX_ROUNDS 10
-#endif
 #pragma unroll
-    for (int r = 0; r < RTX_EXP_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -512,9 +509,6 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         // lowest accepted try, the same point the sequential loop returns (try 20 is always accepted, utils.cu:80).
         V3    rnd = mk(0, 0, 0);
         float glass_u = 0.0f;
-#ifdef RTX_EXP_DOUBLE_RNG
-        for (int rep_ = 0; rep_ < 2; ++rep_)
-#endif
         {
             const bool is_glass = hit && mtype == RTX_MATERIAL_GLASS;
             bool       pending  = hit && (mtype == RTX_MATERIAL_DIFFUSE || mtype == RTX_MATERIAL_METAL || is_glass);
