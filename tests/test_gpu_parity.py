@@ -77,3 +77,20 @@ def test_recursive_against_oracle(ra, ctx, oracle, golden_scenes, cols, rows, sp
     assert (bits(accum) == bits(o_accum)).all()
     for k in ("samples", "rays", "sphere_tests", "term_miss", "term_absorb", "term_depth"):
         assert st[k] == o_st[k], k
+
+
+def test_psnr_against_unmodified_reference_render(ra, ctx, oracle, golden_scenes):
+    """BASELINE's image bar: the unmodified renderScene of the reference (its own mt19937 stream, 1024 spp, fixture made by
+    oracle/gen_fixtures.py) and the HIP backend (Philox, 8192 spp) are independent Monte Carlo estimates of one image and
+    must agree to >= 40 dB."""
+    import json, os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "refrender.json")) as fjs:
+        m = json.load(fjs)["book1_120x80_spp1024"]
+    ref = np.load(os.path.join(GOLDEN, "refrender_book1_120x80_spp1024.npz"))["fb"]
+    spp = 8192
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(m["cols"], m["rows"]))
+    ctx.render(m["cols"], m["rows"], 0, spp, m["max_depth"], 11, want_stats=False)
+    psnr, rmse = oracle.psnr_rgb8(ctx.resolve(spp), ref)
+    assert psnr >= 40.0, (psnr, rmse)
