@@ -79,18 +79,19 @@ def test_recursive_against_oracle(ra, ctx, oracle, golden_scenes, cols, rows, sp
         assert st[k] == o_st[k], k
 
 
-def test_psnr_against_unmodified_reference_render(ra, ctx, oracle, golden_scenes):
-    """BASELINE's image bar: the unmodified renderScene of the reference (its own mt19937 stream, 1024 spp, fixture made by
-    oracle/gen_fixtures.py) and the HIP backend (Philox, 8192 spp) are independent Monte Carlo estimates of one image and
-    must agree to >= 40 dB."""
+@pytest.mark.parametrize("name", ["book1_120x80_spp1024", "glass_120x80_spp1024", "book1_120x80_spp1024_recursive"])
+def test_psnr_against_unmodified_reference_render(ra, ctx, oracle, golden_scenes, name):
+    """BASELINE's image bar: the unmodified renderScene of the reference (its own mt19937 stream, 1024 spp, fixtures made by
+    oracle/gen_fixtures.py / gen_refrenders.py; iterative and -r) and the HIP backend (Philox, 8192 spp) are independent
+    Monte Carlo estimates of one image and must agree to >= 40 dB."""
     import json, os
     from conftest import GOLDEN
     with open(os.path.join(GOLDEN, "refrender.json")) as fjs:
-        m = json.load(fjs)["book1_120x80_spp1024"]
-    ref = np.load(os.path.join(GOLDEN, "refrender_book1_120x80_spp1024.npz"))["fb"]
+        m = json.load(fjs)[name]
+    ref = np.load(os.path.join(GOLDEN, "refrender_" + name + ".npz"))["fb"]
     spp = 8192
-    ctx.upload_scene(golden_scenes["book1"])
+    ctx.upload_scene(golden_scenes[m["scene"]])
     ctx.set_camera(ra.book_camera(m["cols"], m["rows"]))
-    ctx.render(m["cols"], m["rows"], 0, spp, m["max_depth"], 11, want_stats=False)
+    ctx.render(m["cols"], m["rows"], 0, spp, m["max_depth"], 11, flags=ra.FLAG_RECURSIVE if m.get("recursive") else 0, want_stats=False)
     psnr, rmse = oracle.psnr_rgb8(ctx.resolve(spp), ref)
-    assert psnr >= 40.0, (psnr, rmse)
+    assert psnr >= 40.0, (name, psnr, rmse)
