@@ -41,13 +41,13 @@ def cpu_baseline(table, seconds_budget=20.0):
     t0 = time.perf_counter()
     _, _, st = pyoracle.render(table, cam, ROWS, COLS, 0, spp, DEPTH, SEED, nthreads=cores, tile=64)
     dt = time.perf_counter() - t0
-    # the same renderer on ONE thread (SURVEY s8(d) asks for both figures): a 1200 x 40 strip sized to about 3 s
+    # the same renderer on ONE thread (SURVEY s8(d) asks for both figures): the full view at 1200 x 40, sized to about 3 s
     strip_spp = int(max(4, min(16, 3.0 // max(strip * cores, 1e-3))))
     t1 = time.perf_counter()
     _, _, st1 = pyoracle.render(table, cam, 40, COLS, 0, strip_spp, DEPTH, SEED, nthreads=1, tile=40)
     dt1 = time.perf_counter() - t1
     return {"value": round(st["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "single_thread": {"value": round(st1["samples"] / dt1 / 1e6, 4), "sample": "top 1200x40 strip, %d spp (%.1f s)" % (strip_spp, dt1)},
+            "single_thread": {"value": round(st1["samples"] / dt1 / 1e6, 4), "sample": "full view at 1200x40, %d spp (%.1f s)" % (strip_spp, dt1)},
             "mrays_per_s": round(st["rays"] / dt / 1e6, 4),
             "sample": "book1 %dx%d, %d spp, depth %d, 64x64 tile jobs on %d threads (%.1f s)" % (COLS, ROWS, spp, DEPTH, cores, dt)}
 
