@@ -319,12 +319,16 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     const uint32_t max_grid = (uint32_t)c->num_cu * (uint32_t)occ;
     const uint64_t lanes    = (uint64_t)max_grid * block;
 
-    // sample chunking: enough work items for dynamic balance and a short tail, few enough to keep the partial
-    // buffer small.  One chunk reproduces the reference's summation order exactly.
+    // sample chunking: one chunk reproduces the reference's summation order exactly; the automatic choice trades that for
+    // a short tail.  When the work counter runs dry every lane still finishes its current (and its wave's prefetched)
+    // item while more and more lanes idle, so the kernel loses about two item durations: 12 ms of 75 with 56-sample
+    // items on the bench frame, 1 ms with 8-sample ones (profiles/r01e_item_granularity.txt).  256 items per lane keep that
+    // loss under 1 %; at most 64 chunks keep the partial sums (16 B x pixels x chunks) at 1 GB for 1200 x 800.
     if (chunk_spp == 0) {
-        uint64_t want_items = lanes * 32;
-        uint64_t nch = (want_items + npix - 1) / npix;
-        nch = std::max<uint64_t>(1, std::min<uint64_t>(nch, std::min<uint64_t>(spp_count, 64)));
+        const uint64_t per_lane  = getenv("RTX_ITEMS_PER_LANE") ? (uint64_t)atoi(getenv("RTX_ITEMS_PER_LANE")) : 256u;
+        const uint64_t max_chunk = getenv("RTX_MAX_CHUNKS") ? (uint64_t)atoi(getenv("RTX_MAX_CHUNKS")) : 64u;
+        uint64_t nch = (lanes * per_lane + npix - 1) / npix;
+        nch = std::max<uint64_t>(1, std::min<uint64_t>(nch, std::min<uint64_t>(spp_count, std::max<uint64_t>(max_chunk, 1))));
         chunk_spp = (uint32_t)((spp_count + nch - 1) / nch);
     }
     if (chunk_spp > spp_count) chunk_spp = spp_count;

@@ -14,7 +14,7 @@ namespace rtx
 // the <= 34 ulp that the reference's own rounding of b*b - a*c can move the sign of the discriminant.
 constexpr float    kEps        = 7.62939453125e-06f;  // 2^-17
 constexpr uint32_t kMaxBlock   = 512;                  // threads per workgroup (launch bound); the block size is chosen per launch
-constexpr uint32_t kWaveBatch  = 256;                  // work items a wave reserves per trip to the global counter
+constexpr uint32_t kWaveBatch  = 64;                    // work items a wave reserves per trip to the global counter
 constexpr uint32_t kWaveLdsBytes = 4608;               // per wave: 64 ray records (2 KB), 64 result slots (512 B), 256 candidate entries (1 KB), 128 sign-word entries (1 KB)
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
 // MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) + kMfmaAbsMargin / scale^2 per sphere and gamma * |o|^2 per
