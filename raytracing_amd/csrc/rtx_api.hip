@@ -329,6 +329,7 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         const uint64_t max_chunk = getenv("RTX_MAX_CHUNKS") ? (uint64_t)atoi(getenv("RTX_MAX_CHUNKS")) : 64u;
         uint64_t nch = (lanes * per_lane + npix - 1) / npix;
         nch = std::max<uint64_t>(1, std::min<uint64_t>(nch, std::min<uint64_t>(spp_count, std::max<uint64_t>(max_chunk, 1))));
+        nch = std::max<uint64_t>(1, std::min<uint64_t>(nch, ((1ull << 31) - 1) / npix));      // item indices are 31 bits
         chunk_spp = (uint32_t)((spp_count + nch - 1) / nch);
     }
     if (chunk_spp > spp_count) chunk_spp = spp_count;
