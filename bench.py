@@ -92,13 +92,14 @@ def main():
     import raytracing_amd as ra
     from raytracing_amd.multi_gpu import TorchAccum
 
-    torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
-    if use_dist:
+    if use_dist:                                                 # before the first HIP call: the runtime reads these at start-up
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")            # only reached unset in the 1-rank --force-dist rehearsal
-        os.environ.setdefault("NCCL_DEBUG", "WARN")              # keep RCCL's banner off stdout: rank 0 prints one JSON line
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only mode the host driver supports)
+    torch.cuda.set_device(local_rank)
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cols, rows, spp = args.cols, args.rows, args.spp
