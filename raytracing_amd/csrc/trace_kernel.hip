@@ -63,8 +63,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        // hi ^ c ^ key in one instruction (v_bitop3_b32, truth table 0x96 = a ^ b ^ c); the compiler emits two v_xor
+        uint32_t n0, n2;
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"((uint32_t)(p1 >> 32)), "v"(c1), "s"(k0));
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"((uint32_t)(p0 >> 32)), "v"(c3), "s"(k1));
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
