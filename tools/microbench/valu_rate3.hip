@@ -41,13 +41,23 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 #define T_ADDC(D)   "v_addc_co_u32 " #D ", vcc, " #D ", %8, vcc\n"
 #define T_MBCNT(D)  "v_mbcnt_lo_u32_b32 " #D ", %8, " #D "\n"
 #define T_BFE(D)    "v_bfe_u32 " #D ", " #D ", 7, 5\n"
+#define T_BITOP3(D) "v_bitop3_b32 " #D ", " #D ", %8, %9 bitop3:0x96\n"
+#define T_ADDU(D)   "v_add_u32 " #D ", " #D ", %8\n"
+#define T_ADDF(D)   "v_add_f32 " #D ", " #D ", %8\n"
+#define T_OR(D)     "v_or_b32 " #D ", " #D ", %8\n"
+#define T_LSHL(D)   "v_lshlrev_b32 " #D ", 1, " #D "\n"
+#define T_MINF(D)   "v_min_f32 " #D ", " #D ", %8\n"
+#define T_CVTF16(D) "v_cvt_f16_f32 " #D ", " #D "\n"
+#define T_CNDV(D)   "v_cndmask_b32 " #D ", " #D ", %8, vcc\n"
+#define T_FMAC(D)   "v_fmac_f32 " #D ", %8, %9\n"
+#define T_SUBU(D)   "v_sub_u32 " #D ", " #D ", %8\n"
 
 enum { R_FP8, R_FP8HI, R_FP4, R_BF16, R_ANDOR, R_LSHLOR, R_PERM, R_MIN3, R_BFI, R_CMP, R_LSHR, R_OR3, R_U8, R_MAX, R_AND, R_LSHLADD, R_ADD3, R_SWAP, R_FFBL, R_CMPCLS,
-       R_ASHR, R_MUL, R_MULLEG, R_CVTI, R_SAD, R_ADDCO, R_ADDC, R_MBCNT, R_BFE, R_COUNT,
+       R_ASHR, R_MUL, R_MULLEG, R_CVTI, R_SAD, R_ADDCO, R_ADDC, R_MBCNT, R_BFE, R_BITOP3, R_ADDU, R_ADDF, R_OR, R_LSHL, R_MINF, R_CVTF16, R_CNDV, R_FMAC, R_SUBU, R_COUNT,
        T_ALIGN = 100, T_FP8CAP, T_FP4CAP, T_MFMAONLY };
 static const char* rnames[] = { "v_cvt_pk_fp8_f32", "v_cvt_pk_fp8_f32 op_sel hi", "v_cvt_scalef32_pk_fp4_f32", "v_cvt_pk_bf16_f32", "v_and_or_b32", "v_lshl_or_b32", "v_perm_b32", "v_min3_f32",
                                 "v_bfi_b32", "v_cmp_lt_f32", "v_lshrrev_b32", "v_or3_b32", "v_cvt_pk_u8_f32", "v_max_f32", "v_and_b32", "v_lshl_add_u32", "v_add3_u32", "v_permlane32_swap_b32",
-                                "v_ffbl_b32", "v_cmp_class_f32", "v_ashrrev_i32", "v_mul_f32", "v_mul_legacy_f32", "v_cvt_i32_f32", "v_sad_u32", "v_add_co_u32", "v_addc_co_u32", "v_mbcnt_lo", "v_bfe_u32" };
+                                "v_ffbl_b32", "v_cmp_class_f32", "v_ashrrev_i32", "v_mul_f32", "v_mul_legacy_f32", "v_cvt_i32_f32", "v_sad_u32", "v_add_co_u32", "v_addc_co_u32", "v_mbcnt_lo", "v_bfe_u32", "v_bitop3_b32", "v_add_u32", "v_add_f32", "v_or_b32", "v_lshlrev_b32", "v_min_f32", "v_cvt_f16_f32", "v_cndmask_b32 (vcc)", "v_fmac_f32", "v_sub_u32" };
 
 template <int MODE>
 __global__ void __launch_bounds__(256) bench(float* out, int iters, unsigned long long* clk)
@@ -89,6 +99,16 @@ __global__ void __launch_bounds__(256) bench(float* out, int iters, unsigned lon
         else if (MODE == R_ADDC) OP8(T_ADDC);
         else if (MODE == R_MBCNT) OP8(T_MBCNT);
         else if (MODE == R_BFE) OP8(T_BFE);
+        else if (MODE == R_BITOP3) OP8(T_BITOP3);
+        else if (MODE == R_ADDU) OP8(T_ADDU);
+        else if (MODE == R_ADDF) OP8(T_ADDF);
+        else if (MODE == R_OR) OP8(T_OR);
+        else if (MODE == R_LSHL) OP8(T_LSHL);
+        else if (MODE == R_MINF) OP8(T_MINF);
+        else if (MODE == R_CVTF16) OP8(T_CVTF16);
+        else if (MODE == R_CNDV) OP8(T_CNDV);
+        else if (MODE == R_FMAC) OP8(T_FMAC);
+        else if (MODE == R_SUBU) OP8(T_SUBU);
         else {
             // one f16 filter tile: 64 rays x 32 spheres.  h form -> w = oo - h^2 -> c form on top -> signs.
             const f16v zero = {0};
@@ -176,12 +196,17 @@ int main()
     CHECK(hipMalloc(&out, 1024)); CHECK(hipMalloc(&clk, 256 * 16 * 2 * sizeof(unsigned long long)));
     const int iters = 20000;
 #define RATE(M) run<M>(4, iters, out, clk, rnames[M], 8); run<M>(8, iters, out, clk, rnames[M], 8);
+#ifndef ONLY_NEW
     RATE(R_FP8) RATE(R_FP8HI) RATE(R_FP4) RATE(R_BF16) RATE(R_ANDOR) RATE(R_LSHLOR) RATE(R_PERM) RATE(R_MIN3) RATE(R_BFI) RATE(R_CMP) RATE(R_LSHR) RATE(R_OR3) RATE(R_U8) RATE(R_MAX)
     RATE(R_AND) RATE(R_LSHLADD) RATE(R_ADD3) RATE(R_SWAP) RATE(R_FFBL) RATE(R_CMPCLS) RATE(R_ASHR) RATE(R_MUL) RATE(R_MULLEG) RATE(R_CVTI) RATE(R_SAD) RATE(R_ADDCO) RATE(R_ADDC) RATE(R_MBCNT) RATE(R_BFE)
+#endif
+    RATE(R_BITOP3) RATE(R_ADDU) RATE(R_ADDF) RATE(R_OR) RATE(R_LSHL) RATE(R_MINF) RATE(R_CVTF16) RATE(R_CNDV) RATE(R_FMAC) RATE(R_SUBU)
+#ifndef ONLY_NEW
 #define TILE(M, NAME) run<M>(2, iters, out, clk, NAME, 1); run<M>(3, iters, out, clk, NAME, 1); run<M>(4, iters, out, clk, NAME, 1); run<M>(8, iters, out, clk, NAME, 1);
     TILE(T_MFMAONLY, "f16 tile 64x32: 4 mfma only")
     TILE(T_ALIGN, "f16 tile 64x32: 4 mfma + 32 fma + 32 alignbit")
     TILE(T_FP8CAP, "f16 tile 64x32: fp8 sign capture")
     TILE(T_FP4CAP, "f16 tile 64x32: fp4 sign capture")
+#endif
     return 0;
 }
