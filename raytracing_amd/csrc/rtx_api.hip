@@ -300,18 +300,32 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         }
         if (!fits) filter = kFilterValu;
     }
-    const bool   lds_table = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
-    // workgroup size: the one that keeps the most waves resident per SIMD (the LDS-resident table is per workgroup, so a
-    // larger group amortises it over more waves); RTX_BLOCK overrides
-    uint32_t block = 0u;
-    if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) block = (uint32_t)v; }
-    if (!block) {
-        uint32_t best_waves = 0;
+    // Table placement and workgroup size: the MFMA filter's table is staged into LDS only while that does not cost resident waves --
+    // an L2-fed table with 4 waves/SIMD beats an LDS-resident one with 2 (677 spheres: 17.5 against 20.9 ms per 100 spp;
+    // with equal occupancy LDS wins by 7 %).  The group size is the one that keeps the most waves resident (the LDS table
+    // is per workgroup, so a larger group amortises it over more waves).  RTX_BLOCK overrides the group size.
+    const bool lds_fits = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
+    uint32_t forced = 0u;
+    if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) forced = (uint32_t)v; }
+    auto best_block = [&](bool lds, uint32_t* waves_out) -> uint32_t {
+        uint32_t best = 0u, best_waves = 0u;
         for (uint32_t cand : { 512u, 256u }) {
-            const size_t lb = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, cand);
-            const uint32_t waves = (uint32_t)trace_occupancy(filter, lds_table, lb, cand) * (cand / 64u);
-            if (waves > best_waves) { best_waves = waves; block = cand; }
+            if (forced && cand != 512u) break;
+            const uint32_t blk = forced ? forced : cand;
+            const size_t lb = trace_lds_bytes(filter, lds, c->n, c->n_pad, c->n_pad_mfma, blk);
+            const uint32_t waves = (uint32_t)trace_occupancy(filter, lds, lb, blk) * (blk / 64u);
+            if (waves > best_waves) { best_waves = waves; best = blk; }
         }
+        *waves_out = best_waves;
+        return best;
+    };
+    uint32_t waves_global = 0u, waves_lds = 0u;
+    uint32_t block = best_block(false, &waves_global);
+    bool     lds_table = false;
+    if (lds_fits) {
+        const uint32_t block_lds = best_block(true, &waves_lds);
+        // the VALU filter reads one sphere per instruction from the table: for it LDS residency matters more than waves
+        if (filter == kFilterValu || waves_lds >= waves_global) { lds_table = true; block = block_lds; }
     }
     size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, block);
     if (const char* pad = getenv("RTX_LDS_PAD")) lds_bytes += (size_t)atoi(pad);      // tuning aid: lowers the occupancy

@@ -31,7 +31,10 @@ constexpr float    kGammaRay   = 1.52587890625e-05f * 1.0625f;   // 2^-16 plus r
 constexpr double   kGammaSphere = 1.52587890625e-05;
 enum FilterKind { kFilterValu = 0, kFilterMfma = 1 };
 constexpr uint32_t kMaxLdsSpheres = 2048;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
-constexpr uint32_t kMaxLdsSpheresMfma = 1024;          // MFMA filter: 64 B/sphere (+ 16 B exact record)
+#ifndef RTX_MAX_LDS_MFMA
+#define RTX_MAX_LDS_MFMA 1024
+#endif
+constexpr uint32_t kMaxLdsSpheresMfma = RTX_MAX_LDS_MFMA;          // MFMA filter: 64 B/sphere (+ 16 B exact record)
 
 enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStFilterMiss, kStCount };
 
