@@ -114,3 +114,23 @@ def test_spp_partition():
         for (b0, c0), (b1, _) in zip(parts, parts[1:]):
             assert b0 + c0 == b1
         assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_dropin_demo_fails_loudly_without_a_gpu(tmp_path, oracle, golden_scenes):
+    """The reference's own types through renderSceneHIP (oracle/_ref/dropin_demo): on a box without a GPU the call must
+    fail with the library's message -- there is no CPU path to fall back to."""
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "oracle", "_ref", "dropin_demo")
+    if not os.path.exists(demo):
+        pytest.skip("oracle/_ref/dropin_demo is built only where the reference tree exists")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: tests/test_gpu_dropin.py covers the working case")
+    except ImportError:
+        pass
+    scene_bin = tmp_path / "scene.bin"
+    oracle.write_scene_bin(str(scene_bin), golden_scenes["book1"])
+    r = subprocess.run([demo, str(scene_bin), str(tmp_path / "o.fb"), "32", "16", "1", "3", "0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no HIP device" in r.stdout + r.stderr
