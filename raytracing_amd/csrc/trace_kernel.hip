@@ -3,23 +3,24 @@
 // What it replaces (reference file:line):
 //   _renderJob's sample loop           raytracer.cpp:157-186      -> persistent waves, one path per lane, lane refill
 //   thread_pool tile jobs              raytracer.cpp:93-127       -> work items (sample chunk, pixel) drawn from one
-//                                                                   global counter, 256 at a time per wave
-//   Camera::getRay                     camera.h:75-86             -> new_sample()
-//   _color (iterative)                 raytracer.cpp:243-273      -> the bounce state kept in each lane
+//                                                                   global counter, 64 at a time per wave
+//   Camera::getRay                     camera.h:75-86             -> phase (B) of the loop
+//   _color / _color_recursive          raytracer.cpp:213-273      -> the bounce state kept in each lane
 //   _sceneHit + sphereHit              raytracer.cpp:285-304,
-//                                      sphere.cpp:68-102          -> conservative candidate filter over the LDS-staged
-//                                                                   sphere table (two forms, below) + exact re-test
-//                                                                   of the few candidates
-//   materialScatter and helpers        material.cu:17-138         -> shade()
-//   random / samplers                  utils.cu:65-94             -> Philox4x32-10 counter stream
+//                                      sphere.cpp:68-102          -> phase (C): conservative candidate filter over the
+//                                                                   whole sphere table + exact re-test of the few
+//                                                                   candidates in wave-wide batches
+//   materialScatter and helpers        material.cu:17-138         -> phase (D)
+//   random / samplers                  utils.cu:65-94             -> Philox4x32-10 counter stream, rejection
+//                                                                   sampling shared by all lanes of the wave
 //
 // Two candidate filters share everything else (select with rtx_set_filter / RTX_FILTER):
 //   kFilterValu  : per lane, per sphere: oc = C - o, h = oc.d', q = |oc|^2 - r^2(1+eps), sign(q - h^2) -> 11 VALU ops
-//   kFilterMfma  : the same two bilinear forms h = C.d' - o.d' and c = K' - 2 o.C + |o|^2 evaluated for 16 spheres x 16
-//                  rays at a time on the matrix cores (v_mfma_f32_16x16x32_bf16); every f32 operand is split exactly
-//                  into three bf16 parts and the 8 significant partial products of each component fill the K = 32
-//                  dimension, so the products are exact and only the f32 accumulation rounds.  An absolute margin
-//                  proportional to |C|^2 + |o|^2 keeps it conservative ("filter margins").
+//   kFilterMfma  : the same test expanded into one quadratic form of the sphere -- ten monomials (C_i C_j, C_i, 1) against
+//                  ten per-ray coefficients -- and evaluated for 32 spheres x 32 rays by two chained
+//                  v_mfma_f32_32x32x16_f16; every factor is split into two f16 parts (22 bits) behind a per-scene
+//                  power-of-two scale, and an absolute margin proportional to |C|^2 + |o|^2 keeps it conservative
+//                  ("filter margins").  The VALU only captures the signs.
 //
 // Numerics: everything that decides a result (camera ray, the exact sphere test, hit point, normal, scatter,
 // background, accumulation) is evaluated in the reference's operation order with contraction OFF, IEEE division and
@@ -48,12 +49,6 @@ __device__ __forceinline__ V3    divs(V3 v, float t) { return mk(v.x / t, v.y / 
 __device__ __forceinline__ V3    neg(V3 v) { return mk(-v.x, -v.y, -v.z); }                             // :30
 __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }    // :68-71
 __device__ __forceinline__ float sqlen(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }              // :42
-__device__ __forceinline__ float len(V3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }         // :41
-__device__ __forceinline__ V3    normalized(V3 v)                                                        // :45-59
-{
-    float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-    return mk(v.x / l, v.y / l, v.z / l);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Random123 constants).  key = seed, counter = (slot, sample, pixel, 0).
