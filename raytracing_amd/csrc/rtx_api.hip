@@ -335,7 +335,7 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
 
     // sample chunking: one chunk reproduces the reference's summation order exactly; the automatic choice trades that for
     // a short tail.  When the work counter runs dry every lane still finishes its current (and its wave's prefetched)
-    // item while more and more lanes idle, so the kernel loses about two item durations: 12 ms of 75 with 56-sample
+    // item while more and more lanes idle, so the kernel loses about five mean item durations (they are heavy-tailed): 12 ms of 75 with 56-sample
     // items on the bench frame, 1 ms with 8-sample ones (profiles/r01e_item_granularity.txt).  256 items per lane keep that
     // loss under 1 %; at most 64 chunks keep the partial sums (16 B x pixels x chunks) at 1 GB for 1200 x 800.
     if (chunk_spp == 0) {
