@@ -142,8 +142,8 @@ int rtx_write_accum(rtx_ctx* ctx, uint32_t cols, uint32_t rows, const float* rgb
 
 /* Progressive / resumable rendering (no counterpart in the reference, whose renderScene is one
  * blocking call): a checkpoint is the accumulation buffer plus what is needed to continue it -- image size, samples
- * done so far, seed, max_depth and flags.  rtx_save_accum writes "RTXACCUM", version 1, those fields (little endian),
- * then rows*cols*3 floats; rtx_load_accum reads one back into the context's accumulation buffer (as rtx_write_accum
+ * done so far, seed, max_depth and flags.  rtx_save_accum writes a 48-byte header ("RTXACCUM", then little-endian u32
+ * version = 1, cols, rows, spp_done, u64 seed, u32 max_depth, flags, two reserved zero words), then rows*cols*3 floats; rtx_load_accum reads one back into the context's accumulation buffer (as rtx_write_accum
  * does) and returns the fields; the caller continues with rtx_render(spp_begin = *spp_done, RTX_FLAG_ACCUMULATE). */
 int rtx_save_accum(rtx_ctx* ctx, const char* path, uint32_t spp_done, uint64_t seed, uint32_t max_depth, uint32_t flags);
 int rtx_load_accum(rtx_ctx* ctx, const char* path, uint32_t* cols, uint32_t* rows, uint32_t* spp_done, uint64_t* seed,

@@ -1,6 +1,8 @@
 """ctypes binding of librtx.so (include/rtx.h) and the host-side mirror of the reference's interface."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -41,6 +43,27 @@ class Stats(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """torch's ROCm wheels bundle their own HIP runtime as torch/lib/libamdhip64.so (soname libamdhip64.so.7, file name
+    without the version).  librtx.so needs libamdhip64.so.7: loaded after torch it binds to torch's copy by soname, but
+    loaded BEFORE torch it brings in /opt/rocm's copy, `import torch` then adds the bundled one as a second runtime in
+    the process, and torch finds no GPU.  Loading the bundled copy first gives one runtime whichever import comes first.
+    RTX_SYSTEM_HIP=1 skips this (processes that never use torch on the GPU)."""
+    if "torch" in sys.modules or os.environ.get("RTX_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        path = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return
+
+
 def lib():
     """Loads librtx.so.  Raises if it has not been built -- there is no other implementation to fall back to."""
     global _lib
@@ -49,6 +72,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RtxError("%s is missing: build it with `make -C raytracing_amd/csrc` (or __graft_entry__.build()); "
                        "raytracing_amd has no CPU fallback" % LIB_PATH)
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     P, u32, u64, f32 = C.POINTER, C.c_uint32, C.c_uint64, C.c_float
     fp, up = P(f32), P(u32)

@@ -208,6 +208,7 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
         tabA[((size_t)2u * t + 1u) * 64u + 32u + r] = group(plx, ply, lz2);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_scene = false;                                          // a failure below must not leave a half-replaced scene renderable
     if (c->hot_mfma) (void)hipFree(c->hot_mfma);
     c->hot_mfma = nullptr;
     HIP_TRY(hipMalloc(&c->hot_mfma, tabA.size() * sizeof(uint4)));
@@ -215,7 +216,7 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     if (c->hot) (void)hipFree(c->hot);
     if (c->exact) (void)hipFree(c->exact);
     if (c->mat) (void)hipFree(c->mat);
-    c->hot = nullptr; c->exact = nullptr; c->mat = nullptr; c->have_scene = false;
+    c->hot = nullptr; c->exact = nullptr; c->mat = nullptr;
     HIP_TRY(hipMalloc(&c->hot, std::max<size_t>(n_pad, 32) * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->exact, exact.size() * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->mat, mat.size() * sizeof(uint4)));
@@ -517,12 +518,13 @@ extern "C" int rtx_write_accum(rtx_ctx* c, uint32_t cols, uint32_t rows, const f
 }
 
 namespace {
-struct AccumHeader {          // little endian on disk, 44 bytes
+struct AccumHeader {          // little endian on disk, 48 bytes, no implicit padding
     char     magic[8];
     uint32_t version, cols, rows, spp_done;
     uint64_t seed;
-    uint32_t max_depth, flags, reserved;
+    uint32_t max_depth, flags, reserved[2];
 };
+static_assert(sizeof(AccumHeader) == 48, "checkpoint header layout");
 }
 
 extern "C" int rtx_save_accum(rtx_ctx* c, const char* path, uint32_t spp_done, uint64_t seed, uint32_t max_depth, uint32_t flags)

@@ -45,3 +45,34 @@ def test_cli_progressive_resume(tmp_path):
     assert r.returncode == 0 and "resuming" in r.stdout and r.stdout.count("pass done") == 1, r.stdout + r.stderr
     assert open(a, "rb").read() == open(b, "rb").read()
     assert open(a, "rb").read().startswith(b"P6\n64 40\n255\n")
+
+
+def test_render_dist_matches_rtx_cli_and_resumes(tmp_path):
+    """python -m raytracing_amd.render_dist (the multi-GPU host; one rank here): same image file as rtx_cli for the same
+    passes, checkpoints written by one are resumed by the other, a finished job resumed only rewrites its image."""
+    import sys
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    common = ["-w", "64", "-h", "40", "-m", "6", "-s", "3", "-p", "2", "-6", "-r"]
+    dist_cmd = [sys.executable, "-m", "raytracing_amd.render_dist"] + common
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    a, b, ck = tmp_path / "a.ppm", tmp_path / "b.ppm", tmp_path / "b.accum"
+    r = subprocess.run([cli] + common + ["-a", "6", "-f", str(a)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(dist_cmd + ["-a", "4", "-f", str(b), "-k", str(ck)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.count("pass done") == 2 and ck.exists(), r.stdout + r.stderr
+    # resumed by the C++ host: the checkpoint format is shared
+    r = subprocess.run([cli] + common + ["-a", "6", "-f", str(b), "-k", str(ck), "-R"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "resuming" in r.stdout and r.stdout.count("pass done") == 1, r.stdout + r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+    # ... and the finished job resumed by the Python host renders nothing and writes the same image
+    os.remove(b)
+    r = subprocess.run(dist_cmd + ["-a", "6", "-f", str(b), "-k", str(ck), "-R"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "resuming" in r.stdout and "at 6 of 6" in r.stdout, r.stdout + r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+    # a checkpoint that is further along than the job asked for is not continued
+    r = subprocess.run(dist_cmd + ["-a", "2", "-f", str(b), "-k", str(ck), "-R"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "starting over" in r.stdout and r.stdout.count("pass done") == 1, r.stdout + r.stderr
+    r = subprocess.run([cli] + common + ["-a", "2", "-f", str(a)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and open(a, "rb").read() == open(b, "rb").read()

@@ -218,3 +218,18 @@ def test_full_size_properties(ra, ctx, golden_scenes):
     fb = ctx.resolve(spp)
     top = ((fb.reshape(rows, cols)[:40] >> 8) & 0xFF).mean()           # sky rows: blue channel near 255
     assert top > 230 and (fb & 0xFF == 0).all()
+
+
+@pytest.mark.parametrize("torch_first", [False, True])
+def test_one_hip_runtime_whichever_import_comes_first(torch_first):
+    """torch bundles its own libamdhip64; librtx must share it, or a process that creates a context and THEN imports
+    torch ends with two runtimes and torch sees no GPU (api._share_torch_hip_runtime)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    use_rtx = "import raytracing_amd as ra; c = ra.Context(0); c.close()"
+    use_torch = "import torch; assert float(torch.ones(4, device='cuda:0').sum().item()) == 4.0"
+    code = "; ".join([use_torch, use_rtx] if torch_first else [use_rtx, use_torch])
+    code += "; m = open('/proc/self/maps').read(); n = len({l.split()[-1] for l in m.splitlines() if 'libamdhip64' in l}); assert n == 1, n"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
