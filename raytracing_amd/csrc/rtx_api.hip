@@ -462,10 +462,10 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         unsigned long long h[kStCount + 12];
         HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
         if (getenv("RTX_PRINT_PHASES")) {
-            static const char* names[12] = { "A fetch", "B camera", "C filter tiles", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish", "C filter setup", "C extract", "-", "-" };
+            static const char* names[12] = { "A fetch", "B camera", "C filter tiles", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish", "C filter setup", "C push words", "C peel + enqueue", "C exact batches" };
             unsigned long long tot = 0;
             for (int k = 0; k < 12; ++k) tot += h[kStCount + k];
-            for (int k = 0; k < 10 && tot; ++k) fprintf(stderr, "phase %-14s %6.2f %%\n", names[k], 100.0 * (double)h[kStCount + k] / (double)tot);
+            for (int k = 0; k < 12 && tot; ++k) fprintf(stderr, "phase %-18s %6.2f %%\n", names[k], 100.0 * (double)h[kStCount + k] / (double)tot);
         }
         memset(stats, 0, sizeof(*stats));
         if (max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE)) {

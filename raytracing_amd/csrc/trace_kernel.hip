@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             uint32_t q_head = 0, q_count = 0;          // wave-uniform
             res[lane] = 0x7F7FFFFFFFFFFFFFull;         // (FLT_MAX, kNoHit): raytracer.cpp:251
             auto run_batch = [&](uint32_t nb) {
+                RTX_STAMP(10);
                 if (lane < nb) {
                     const uint32_t ent = queue[(q_head + lane) & 255u];
                     const uint32_t ray = ent >> 26;
@@ -293,6 +294,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 q_head += nb;
                 q_count -= nb;
                 c_cand += nb;
+                RTX_STAMP(11);
             };
             // the ring holds 256 entries: at most 63 are pending after the drain, one call adds at most 64
             auto enqueue = [&](bool has, uint32_t entry) {
@@ -316,6 +318,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     enqueue(w != 0u, code | (uint32_t)__builtin_ctz(w | 0x80000000u));
                     w &= w - 1u;
                 }
+                RTX_STAMP(10);
             };
             auto push_word = [&](uint32_t wv, uint32_t code) {
                 const uint64_t m = __ballot(wv != 0u);
