@@ -308,29 +308,36 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     const bool lds_fits = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
     uint32_t forced = 0u;
     if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) forced = (uint32_t)v; }
-    auto best_block = [&](bool lds, uint32_t* waves_out) -> uint32_t {
+    auto best_block = [&](int mode, uint32_t* waves_out) -> uint32_t {
         uint32_t best = 0u, best_waves = 0u;
         for (uint32_t cand : { 512u, 256u }) {
             if (forced && cand != 512u) break;
             const uint32_t blk = forced ? forced : cand;
-            const size_t lb = trace_lds_bytes(filter, lds, c->n, c->n_pad, c->n_pad_mfma, blk);
-            const uint32_t waves = (uint32_t)trace_occupancy(filter, lds, lb, blk) * (blk / 64u);
+            const size_t lb = trace_lds_bytes(filter, mode, c->n, c->n_pad, c->n_pad_mfma, blk);
+            const uint32_t waves = (uint32_t)trace_occupancy(filter, mode, lb, blk) * (blk / 64u);
             if (waves > best_waves) { best_waves = waves; best = blk; }
         }
         *waves_out = best_waves;
         return best;
     };
+    // A large table that is not LDS-resident is, for the MFMA filter, streamed through a small LDS stage that the waves of
+    // a workgroup fill together (one L2 read per workgroup instead of one per wave).  The price is a barrier per 128
+    // spheres, i.e. waves in lockstep: measured +8 % at 20 164 spheres, +4 % at 4 901, -4 % at 1 601
+    // (profiles/r01h_*), hence the threshold.  RTX_STREAM=1 / 0 forces it on / off.
+    bool stream_ok = filter == kFilterMfma && c->n_pad_mfma >= 3072u;
+    if (const char* e = getenv("RTX_STREAM")) stream_ok = filter == kFilterMfma && atoi(e) != 0;
+    const int  far_mode  = stream_ok ? kTableStream : kTableGlobal;
     uint32_t waves_global = 0u, waves_lds = 0u;
-    uint32_t block = best_block(false, &waves_global);
-    bool     lds_table = false;
+    uint32_t block = best_block(far_mode, &waves_global);
+    int      table_mode = far_mode;
     if (lds_fits) {
-        const uint32_t block_lds = best_block(true, &waves_lds);
+        const uint32_t block_lds = best_block(kTableLds, &waves_lds);
         // the VALU filter reads one sphere per instruction from the table: for it LDS residency matters more than waves
-        if (filter == kFilterValu || waves_lds >= waves_global) { lds_table = true; block = block_lds; }
+        if (filter == kFilterValu || waves_lds >= waves_global) { table_mode = kTableLds; block = block_lds; }
     }
-    size_t lds_bytes = trace_lds_bytes(filter, lds_table, c->n, c->n_pad, c->n_pad_mfma, block);
+    size_t lds_bytes = trace_lds_bytes(filter, table_mode, c->n, c->n_pad, c->n_pad_mfma, block);
     if (const char* pad = getenv("RTX_LDS_PAD")) lds_bytes += (size_t)atoi(pad);      // tuning aid: lowers the occupancy
-    const int    occ       = trace_occupancy(filter, lds_table, lds_bytes, block);
+    const int    occ       = trace_occupancy(filter, table_mode, lds_bytes, block);
     const uint32_t max_grid = (uint32_t)c->num_cu * (uint32_t)occ;
     const uint64_t lanes    = (uint64_t)max_grid * block;
 
@@ -379,7 +386,7 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     const uint32_t blocks_needed = (uint32_t)((n_items64 + block - 1) / block);
     const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(max_grid, blocks_needed));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
-    HIP_TRY(launch_trace(P, filter, lds_table, validate, grid, block, lds_bytes, c->stream));
+    HIP_TRY(launch_trace(P, filter, table_mode, validate, grid, block, lds_bytes, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     c->ev_trace = true;

@@ -30,6 +30,10 @@ constexpr double   kMfmaAbsMargin = 0.03125;                         // 2^-5
 constexpr float    kGammaRay   = 1.52587890625e-05f * 1.0625f;   // 2^-16 plus room for the rounding of |o|^2 itself
 constexpr double   kGammaSphere = 1.52587890625e-05;
 enum FilterKind { kFilterValu = 0, kFilterMfma = 1 };
+// where the filter's sphere table lives: read through L2 by every wave, resident in LDS, or (MFMA filter) streamed
+// through a double-buffered LDS stage that the waves of a workgroup fill together, 128 spheres at a time
+enum TableMode { kTableGlobal = 0, kTableLds = 1, kTableStream = 2 };
+constexpr uint32_t kStreamStageBytes = 2 * 8192;       // two buffers of one 128-sphere chunk (4 tiles x 2 KB)
 constexpr uint32_t kMaxLdsSpheres = 2048;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
 #ifndef RTX_MAX_LDS_MFMA
 #define RTX_MAX_LDS_MFMA 1024
@@ -58,9 +62,9 @@ struct TraceParams {
     unsigned long long* stats; // kStCount counters
 };
 
-hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, uint32_t block, size_t lds_bytes, hipStream_t stream);
-int  trace_occupancy(int filter, bool lds_table, size_t lds_bytes, uint32_t block);
-size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block);
+hipError_t launch_trace(const TraceParams& p, int filter, int table_mode, bool validate, uint32_t grid, uint32_t block, size_t lds_bytes, hipStream_t stream);
+int  trace_occupancy(int filter, int table_mode, size_t lds_bytes, uint32_t block);
+size_t trace_lds_bytes(int filter, int table_mode, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block);
 void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream);
 void launch_fill(float* accum, uint32_t n_floats, float value, bool accumulate, hipStream_t stream);
 void launch_resolve(const float* accum, uint32_t* fb, uint32_t cols, uint32_t rows, uint32_t spp_total, uint32_t debug_tile, hipStream_t stream);

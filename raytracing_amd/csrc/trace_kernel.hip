@@ -116,9 +116,20 @@ __device__ __forceinline__ uint32_t split_f16_pair(float x)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int FILTER, bool LDS_TABLE, bool VALIDATE>
+// One 16-byte-per-lane global -> LDS copy (1 KB per wave-instruction, no VGPR destination): lane l's 16 bytes land at
+// lds_dst + 16 l.  The compiler does not count it: wait with s_waitcnt vmcnt(0) before the barrier that publishes the data.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int FILTER, int TABLE, bool VALIDATE>
 __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(4))) trace_kernel(const TraceParams P)   // <= 128 VGPRs
 {
+    constexpr bool LDS_TABLE = (TABLE == kTableLds);
+    constexpr bool STREAM    = (TABLE == kTableStream);
+    static_assert(!STREAM || FILTER == kFilterMfma, "only the MFMA filter streams its table");
     extern __shared__ float4 smem[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -136,6 +147,8 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         table = smem;
         exact = smem + table_f4;
         wave_lds = smem + table_f4 + ((P.n + 3u) & ~3u);
+    } else if (STREAM) {
+        wave_lds = smem + kStreamStageBytes / 16u;      // the stage comes first
     } else {
         wave_lds = smem;
     }
@@ -248,7 +261,13 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         RTX_STAMP(1);
         const bool     tracing = (st == kTrace);
         const uint64_t tmask   = __ballot(tracing);
-        if (!tmask) break;      // every lane is kDead: the queue is drained and all paths have ended
+        if (STREAM) {
+            // the waves of a workgroup walk the table together (barriers in the filter loop), so they also stop together;
+            // this barrier also separates the previous iteration's reads of the stage from the next fill
+            if (!__syncthreads_or(tmask != 0ull)) break;
+        } else {
+            if (!tmask) break;      // every lane is kDead: the queue is drained and all paths have ended
+        }
         c_rays += (uint64_t)__popcll(tmask);
 
         // ---- (C) _sceneHit: conservative filter over all spheres, exact re-test of the candidates ----------------
@@ -404,18 +423,42 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 rayrec[lane * 2u + 1u] = make_float4(d.x, d.y, d.z, 0.0f);
 
                 RTX_STAMP(8);
-                h8v A0_next = __builtin_bit_cast(h8v, tabA[0]), A1_next = __builtin_bit_cast(h8v, tabA[64]);
+                // STREAM: the workgroup's waves copy chunk g + 1 (128 spheres = 4 tiles = 8 KB, 1 KB per glds16) into one half of
+                // the stage while everybody filters chunk g out of the other half; one barrier per chunk orders both the
+                // "chunk g has landed" and the "chunk g - 1 is no longer read" directions.
+                const uint32_t nwaves     = blockDim.x >> 6;
+                const uint32_t wave_u     = uniform(wave);
+                const uint32_t stage_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)smem;
+                auto stage_chunk = [&](uint32_t g) {
+                    for (uint32_t u = wave_u; u < 8u; u += nwaves)
+                        glds16(reinterpret_cast<const uint4*>(P.hot_mfma) + ((size_t)g * 8u + u) * 64u + lane, stage_addr + ((g & 1u) << 13) + (u << 10));
+                };
+                if (STREAM && P.n_pad_mfma != 0u) stage_chunk(0u);
+                h8v A0_next, A1_next;
+                if (!STREAM) { A0_next = __builtin_bit_cast(h8v, tabA[0]); A1_next = __builtin_bit_cast(h8v, tabA[64]); }
                 for (uint32_t base = 0; base < P.n_pad_mfma; base += 128u) {
+                    const uint4* stage = reinterpret_cast<const uint4*>(smem) + (((base >> 7) & 1u) << 9) + lane;
+                    if (STREAM) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        if (base + 128u < P.n_pad_mfma) stage_chunk((base >> 7) + 1u);
+                    }
                     uint32_t word[4];
 #pragma unroll
                     for (uint32_t w = 0; w < 2u; ++w) {
                         uint32_t m0 = 0u, m1 = 0u;
 #pragma unroll
                         for (uint32_t tt = 0; tt < 2u; ++tt) {
-                            const h8v A0 = A0_next, A1 = A1_next;
-                            const uint32_t nt = (base >> 5) + 2u * w + tt + 1u;           // the table ends with a spare tile
-                            A0_next = __builtin_bit_cast(h8v, tabA[(2u * nt) * 64u]);
-                            A1_next = __builtin_bit_cast(h8v, tabA[(2u * nt + 1u) * 64u]);
+                            h8v A0, A1;
+                            if (STREAM) {
+                                A0 = __builtin_bit_cast(h8v, stage[(2u * (2u * w + tt)) * 64u]);
+                                A1 = __builtin_bit_cast(h8v, stage[(2u * (2u * w + tt) + 1u) * 64u]);
+                            } else {
+                                A0 = A0_next; A1 = A1_next;
+                                const uint32_t nt = (base >> 5) + 2u * w + tt + 1u;           // the table ends with a spare tile
+                                A0_next = __builtin_bit_cast(h8v, tabA[(2u * nt) * 64u]);
+                                A1_next = __builtin_bit_cast(h8v, tabA[(2u * nt + 1u) * 64u]);
+                            }
                             const f16v zero = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
                             f16v h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0[0], zero, 0, 0, 0);
                             f16v h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0[1], zero, 0, 0, 0);
@@ -721,39 +764,41 @@ __global__ void __launch_bounds__(256) resolve_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int FILTER, bool LDS, bool VAL> static const void* kernel_ptr() { return (const void*)trace_kernel<FILTER, LDS, VAL>; }
+template <int FILTER, int TABLE, bool VAL> static const void* kernel_ptr() { return (const void*)trace_kernel<FILTER, TABLE, VAL>; }
 
-static const void* select_kernel(int filter, bool lds_table, bool validate)
+static const void* select_kernel(int filter, int table_mode, bool validate)
 {
     if (filter == kFilterMfma) {
-        if (lds_table) return validate ? kernel_ptr<kFilterMfma, true, true>() : kernel_ptr<kFilterMfma, true, false>();
-        return validate ? kernel_ptr<kFilterMfma, false, true>() : kernel_ptr<kFilterMfma, false, false>();
+        if (table_mode == kTableStream) return validate ? kernel_ptr<kFilterMfma, kTableStream, true>() : kernel_ptr<kFilterMfma, kTableStream, false>();
+        if (table_mode == kTableLds) return validate ? kernel_ptr<kFilterMfma, kTableLds, true>() : kernel_ptr<kFilterMfma, kTableLds, false>();
+        return validate ? kernel_ptr<kFilterMfma, kTableGlobal, true>() : kernel_ptr<kFilterMfma, kTableGlobal, false>();
     }
-    if (lds_table) return validate ? kernel_ptr<kFilterValu, true, true>() : kernel_ptr<kFilterValu, true, false>();
-    return validate ? kernel_ptr<kFilterValu, false, true>() : kernel_ptr<kFilterValu, false, false>();
+    if (table_mode == kTableLds) return validate ? kernel_ptr<kFilterValu, kTableLds, true>() : kernel_ptr<kFilterValu, kTableLds, false>();
+    return validate ? kernel_ptr<kFilterValu, kTableGlobal, true>() : kernel_ptr<kFilterValu, kTableGlobal, false>();
 }
 
-size_t trace_lds_bytes(int filter, bool lds_table, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block)
+size_t trace_lds_bytes(int filter, int table_mode, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block)
 {
-    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 64 : (size_t)n_pad * 16) : 0;
+    const bool   lds_table = table_mode == kTableLds;
+    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 64 : (size_t)n_pad * 16) : (table_mode == kTableStream ? kStreamStageBytes : 0);
     const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
     return table + exact + (size_t)(block / 64) * kWaveLdsBytes;
 }
 
-int trace_occupancy(int filter, bool lds_table, size_t lds_bytes, uint32_t block)
+int trace_occupancy(int filter, int table_mode, size_t lds_bytes, uint32_t block)
 {
     int blocks = 0;
-    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute(select_kernel(filter, lds_table, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, select_kernel(filter, lds_table, false), (int)block, lds_bytes);
+    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute(select_kernel(filter, table_mode, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, select_kernel(filter, table_mode, false), (int)block, lds_bytes);
     if (e != hipSuccess || blocks < 1) blocks = 1;
     return blocks;
 }
 
-hipError_t launch_trace(const TraceParams& p, int filter, bool lds_table, bool validate, uint32_t grid, uint32_t block, size_t lds_bytes, hipStream_t stream)
+hipError_t launch_trace(const TraceParams& p, int filter, int table_mode, bool validate, uint32_t grid, uint32_t block, size_t lds_bytes, hipStream_t stream)
 {
     TraceParams copy = p;
     void* args[] = { &copy };
-    const void* fn = select_kernel(filter, lds_table, validate);
+    const void* fn = select_kernel(filter, table_mode, validate);
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;

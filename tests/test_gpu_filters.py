@@ -109,3 +109,38 @@ def test_camera_outside_f16_range_uses_valu_filter(ra, oracle, golden_scenes):
     assert s0["candidates"] == s1["candidates"]
     o_accum, o_primary, _ = oracle.render(table, oracle.camera(*args), rows, cols, 0, spp, 50, 5, want_primary=True)
     assert (p1 == o_primary).all() and (bits(a1) == bits(o_accum)).all() and (p0 == p1).all()
+
+
+@pytest.mark.parametrize("scene,cols,rows,spp,block", [("book1", 96, 64, 2, None), ("book1", 96, 64, 2, "256"), ("glass", 64, 40, 3, "128"), ("scaled", 64, 48, 1, None),
+                                                       ("one", 40, 30, 2, None), ("empty", 40, 30, 2, None)])
+def test_streamed_table_equals_the_oracle(ra, oracle, golden_scenes, monkeypatch, scene, cols, rows, spp, block):
+    """The streamed-table mode (workgroup-shared LDS stage, RTX_STREAM=1 forces it for any size) against the oracle, with the
+    full-scan validation on: small tables (4 chunks), the 20 164-sphere table (158 chunks), workgroups of 8, 4 and 2 waves,
+    one sphere, no sphere; and again in the same process without it (the mode is chosen per launch)."""
+    if scene == "one":
+        table = golden_scenes["book1"][:1].copy()
+    elif scene == "empty":
+        table = golden_scenes["book1"][:0].copy()
+    else:
+        table = golden_scenes[scene]
+    monkeypatch.setenv("RTX_STREAM", "1")
+    if block:
+        monkeypatch.setenv("RTX_BLOCK", block)
+    ctx = ra.Context(0)
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    primary, st = ctx.render(cols, rows, 0, spp, 50, 21, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+    accum = ctx.read_accum()
+    assert st["filter_misses"] == 0
+    o_accum, o_primary, o_st = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, 0, spp, 50, 21, want_primary=True)
+    assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+    for k in ("samples", "rays", "term_miss", "term_absorb", "term_depth"):
+        assert st[k] == o_st[k]
+    # the production kernel (no validation scan), automatic chunking, -r
+    _, st2 = ctx.render(cols, rows, 0, spp, 50, 21, flags=ra.FLAG_RECURSIVE)
+    o2, _, _ = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, 0, spp, 50, 21, recursive=True)
+    np.testing.assert_allclose(ctx.read_accum(), o2, rtol=1e-5, atol=1e-6)      # chunked sums round differently
+    monkeypatch.setenv("RTX_STREAM", "0")
+    ctx.render(cols, rows, 0, spp, 50, 21, chunk_spp=spp)
+    assert (bits(ctx.read_accum()) == bits(accum)).all()
+    ctx.close()

@@ -21,5 +21,6 @@ book = ra.random_scene(1)
 run("C2 book1 500spp", book, 1200, 800, 500)
 run("C3 book1 4K (64 of 4096 spp)", book, 3840, 2160, 64)
 run("C4 glass-heavy 100spp", ra.random_scene(1, 11, 0.1, 0.95), 1200, 800, 100)
-run("C5 scaled 20k spheres 8spp", ra.random_scene(1, 71), 1200, 800, 8)
-run("mid 1.6k spheres 20spp", ra.random_scene(1, 20), 1200, 800, 20)
+run("C5 scaled 20k spheres 100spp", ra.random_scene(1, 71), 1200, 800, 100)
+run("mid 1.6k spheres 100spp", ra.random_scene(1, 20), 1200, 800, 100)
+run("mid 5k spheres 50spp", ra.random_scene(1, 35), 1200, 800, 50)
