@@ -134,3 +134,35 @@ def test_dropin_demo_fails_loudly_without_a_gpu(tmp_path, oracle, golden_scenes)
     oracle.write_scene_bin(str(scene_bin), golden_scenes["book1"])
     r = subprocess.run([demo, str(scene_bin), str(tmp_path / "o.fb"), "32", "16", "1", "3", "0"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "no HIP device" in r.stdout + r.stderr
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/rtx.h is the boundary a cgo / JNI / ctypes stub binds: it must compile as strict C99 and the library must
+    link from a C program (no C++ types, no torch types in the signatures)."""
+    import subprocess
+    src = tmp_path / "use_rtx.c"
+    src.write_text(r'''
+#include "rtx.h"
+#include <stdio.h>
+int main(void)
+{
+    rtx_camera cam;
+    const float pos[3] = { 13.0f, 2.0f, 3.0f }, up[3] = { 0.0f, 1.0f, 0.0f }, lookat[3] = { 0.0f, 0.0f, 0.0f };
+    rtx_ctx* ctx = 0;
+    int rc = rtx_camera_init(&cam, 20.0f, 1.5f, 0.1f, 10.0f, pos, up, lookat);
+    if (rc != RTX_OK) return 2;
+    printf("%s lens %.3f cap %u\n", rtx_version(), (double)cam.lens_radius, rtx_scene_capacity(11));
+    rc = rtx_create(0, &ctx);
+    if (rc == RTX_OK) { rtx_destroy(ctx); printf("gpu\n"); return 0; }
+    printf("no gpu: %s\n", rtx_last_error());
+    return 0;
+}
+''')
+    exe = tmp_path / "use_rtx"
+    libdir = os.path.join(ROOT, "raytracing_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lrtx", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "raytracing_amd" in r.stdout and "lens 0.050" in r.stdout and ("gpu" in r.stdout)
