@@ -359,6 +359,13 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     const uint64_t n_items64 = (uint64_t)npix * nchunks;
     if (n_items64 >= (1ull << 31)) return fail(RTX_ERR_ARG, "rtx_render: %llu work items; raise chunk_spp", (unsigned long long)n_items64);
     const uint32_t n_items = (uint32_t)n_items64;
+    // Reservation size: every trip to the one global counter is a device-scope atomic on one address, and 4096 waves taking
+    // 64 one-sample items at a time saturate it (200 spp as 1-sample items: 34.7 ms with 64-item reservations, 24.6 ms with
+    // 256); a wave therefore reserves about 512 samples' worth, at least 64 items (the tail grows with it, see above).
+    uint32_t wave_batch = kWaveBatch;
+    while (wave_batch < 512u && wave_batch * 2u * chunk_spp <= 512u) wave_batch *= 2u;
+    if (const char* e = getenv("RTX_WAVE_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096) wave_batch = (uint32_t)v; }
+    if ((uint64_t)n_items + (uint64_t)max_grid * (block / 64u) * 2u * wave_batch >= (1ull << 32)) return fail(RTX_ERR_ARG, "rtx_render: work counter would overflow; raise chunk_spp");
     rc = ensure(&c->partials, &c->partials_items, (size_t)n_items);
     if (rc) return rc;
     if (want_primary) {
@@ -369,7 +376,7 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     TraceParams P{};
     P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.mfma_scale = c->mfma_scale; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
     P.cols = cols; P.rows = rows; P.npix = npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = nchunks;
-    P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = n_items;
+    P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = n_items; P.wave_batch = wave_batch;
     P.partials = c->partials; P.primary = want_primary ? c->primary : nullptr; P.work_counter = c->work_counter;
     P.stats = want_stats ? c->stats : nullptr;
 

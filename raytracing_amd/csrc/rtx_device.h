@@ -14,7 +14,7 @@ namespace rtx
 // the <= 34 ulp that the reference's own rounding of b*b - a*c can move the sign of the discriminant.
 constexpr float    kEps        = 7.62939453125e-06f;  // 2^-17
 constexpr uint32_t kMaxBlock   = 512;                  // threads per workgroup (launch bound); the block size is chosen per launch
-constexpr uint32_t kWaveBatch  = 64;                    // work items a wave reserves per trip to the global counter
+constexpr uint32_t kWaveBatch  = 64;                    // smallest reservation of work items (TraceParams::wave_batch)
 constexpr uint32_t kWaveLdsBytes = 4608;               // per wave: 64 ray records (2 KB), 64 result slots (512 B), 256 candidate entries (1 KB), 128 sign-word entries (1 KB)
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
 // MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) + kMfmaAbsMargin / scale^2 per sphere and gamma * |o|^2 per
@@ -55,6 +55,7 @@ struct TraceParams {
     uint32_t      spp_begin, spp_count, chunk_spp, nchunks;
     uint32_t      max_depth, key0, key1, flags;
     uint32_t      n_items;
+    uint32_t      wave_batch; // work items a wave reserves per trip to the global counter (host: about 512 samples' worth)
     float4*       partials;   // n_items x (sum r, g, b, 0): item = chunk * npix + pixel
     float4*       att_stack;  // RTX_FLAG_RECURSIVE only: max_depth x (grid * block) attenuations
     uint32_t*     primary;    // NULL or spp_count * npix

@@ -163,10 +163,10 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
 
     // wave-level work reservation: [w_next, w_end) is owned, pf holds the next reservation (lane 0's value)
     uint32_t pf = 0;
-    if (lane == 0) pf = atomicAdd(P.work_counter, kWaveBatch);
+    if (lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
     uint32_t w_next = uniform(pf);
-    uint32_t w_end  = w_next + kWaveBatch;
-    if (lane == 0) pf = atomicAdd(P.work_counter, kWaveBatch);
+    uint32_t w_end  = w_next + P.wave_batch;
+    if (lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
 
     // per-lane path state
     uint32_t st = kNeedItem, item = 0, pix = 0, prow = 0, s_cur = 0, s_end = 0, bounce = 0;
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 uint32_t nb = uniform(pf);
                 it     = (r < avail) ? (w_next + r) : (nb + (r - avail));
                 w_next = nb + (cnt - avail);
-                w_end  = nb + kWaveBatch;
-                if (lane == 0) pf = atomicAdd(P.work_counter, kWaveBatch);
+                w_end  = nb + P.wave_batch;
+                if (lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
             }
             if (st == kNeedItem) {
                 if (it < P.n_items) {
