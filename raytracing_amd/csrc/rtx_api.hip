@@ -361,9 +361,11 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     const uint32_t n_items = (uint32_t)n_items64;
     // Reservation size: every trip to the one global counter is a device-scope atomic on one address, and 4096 waves taking
     // 64 one-sample items at a time saturate it (200 spp as 1-sample items: 34.7 ms with 64-item reservations, 24.6 ms with
-    // 256); a wave therefore reserves about 512 samples' worth, at least 64 items (the tail grows with it, see above).
+    // 256); a wave therefore reserves about 512 samples' worth at 512 spheres, at least 64 items (the tail grows with it, see above).
+    // Larger tables mean longer bounce iterations and fewer trips, so the target shrinks with the table.
     uint32_t wave_batch = kWaveBatch;
-    while (wave_batch < 512u && wave_batch * 2u * chunk_spp <= 512u) wave_batch *= 2u;
+    const uint64_t target = 512ull * 512ull / std::max<uint32_t>(c->n_pad, 512u);
+    while (wave_batch < 512u && (uint64_t)wave_batch * 2u * chunk_spp <= target) wave_batch *= 2u;
     if (const char* e = getenv("RTX_WAVE_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096) wave_batch = (uint32_t)v; }
     if ((uint64_t)n_items + (uint64_t)max_grid * (block / 64u) * 2u * wave_batch >= (1ull << 32)) return fail(RTX_ERR_ARG, "rtx_render: work counter would overflow; raise chunk_spp");
     rc = ensure(&c->partials, &c->partials_items, (size_t)n_items);
