@@ -100,6 +100,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")            # only reached unset in the 1-rank --force-dist rehearsal
         os.environ.setdefault("NCCL_DEBUG", "WARN")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only mode the host driver supports)
+    if torch.cuda.device_count() > 0:
+        local_rank %= torch.cuda.device_count()      # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))

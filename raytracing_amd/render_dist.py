@@ -58,6 +58,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_DEBUG", "WARN")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() > 0:
+        local_rank %= torch.cuda.device_count()      # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
