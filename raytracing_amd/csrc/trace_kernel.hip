@@ -652,8 +652,13 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 ended = true; depth_end = true;
                 thr   = mk(0, 0, 0);
             } else if (ok) {
-                if (recursive) att_stack[(size_t)bounce * stack_stride] = make_float4(att.x, att.y, att.z, 0.0f);
-                else           thr = mul(thr, att);                       // color *= attenuation
+                if (recursive) {
+                    // the outermost attenuation stays in the (otherwise idle) throughput registers, the rest goes to the stack
+                    if (bounce == 0u) thr = att;
+                    else              att_stack[(size_t)(bounce - 1u) * stack_stride] = make_float4(att.x, att.y, att.z, 0.0f);
+                } else {
+                    thr = mul(thr, att);                                  // color *= attenuation
+                }
                 o = hp;
                 d = nd_;
                 bounce++;
@@ -668,19 +673,17 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             float t    = 0.5f * (unit.y + 1.0f);
             V3    bg   = add(scale(1.0f - t, mk(1.0f, 1.0f, 1.0f)), scale(t, mk(0.5f, 0.7f, 1.0f)));
             if (!recursive) thr = mul(thr, bg);
-            else            thr = bg;
             ended = true;
-        }
-        if (recursive) {
-            // -r unwinds the recursion: attenuation * (attenuation * (... * background)), innermost product first
-            // (raytracer.cpp:232), which rounds differently from the iterative running product
-            uint32_t k = (tracing && !hit) ? bounce : 0u;
-            while (__ballot(k > 0u)) {
-                if (k > 0u) {
+            if (recursive) {
+                // -r unwinds the recursion: attenuation * (attenuation * (... * background)), innermost product first
+                // (raytracer.cpp:232), which rounds differently from the iterative running product
+                uint32_t k = bounce > 0u ? bounce - 1u : 0u;                // entries on the stack
+                while (k > 0u) {                                            // (divergent loop: lanes leave as they finish)
                     --k;
                     const float4 at = att_stack[(size_t)k * stack_stride];
-                    thr = mul(mk(at.x, at.y, at.z), thr);
+                    bg = mul(mk(at.x, at.y, at.z), bg);
                 }
+                thr = bounce > 0u ? mul(thr, bg) : bg;
             }
         }
         // early-terminated-path accounting: one ballot + popcount per cause, kept in wave-uniform registers
