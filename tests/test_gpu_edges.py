@@ -220,6 +220,59 @@ def test_full_size_properties(ra, ctx, golden_scenes):
     assert top > 230 and (fb & 0xFF == 0).all()
 
 
+def test_bench_workload_properties(ra, ctx, golden_scenes):
+    """The bench workload itself (BASELINE configuration 2: 1200x800, 500 spp, depth 50): exact counters, bit-for-bit
+    repeatability, additivity over a split of the sample range (two chunks of 250 = two accumulated launches of 250), and
+    agreement of the automatic chunking (64 chunks, another summation order) to float accuracy."""
+    cols, rows, spp = 1200, 800, 500
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(cols, rows))
+    _, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=250)
+    whole = ctx.read_accum()
+    assert st["samples"] == cols * rows * spp and st["filter_misses"] == 0
+    assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
+    assert st["sphere_tests"] == st["rays"] * 485 and 2.7 < st["rays"] / st["samples"] < 2.8
+    assert st["candidates"] < 2.2 * st["rays"]                           # the filter passes about two spheres per ray on
+    _, st2 = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=250)
+    assert (bits(ctx.read_accum()) == bits(whole)).all() and st2["rays"] == st["rays"]
+    ctx.render(cols, rows, 0, 250, 50, 1, chunk_spp=250, want_stats=False)
+    ctx.render(cols, rows, 250, 250, 50, 1, flags=ra.FLAG_ACCUMULATE, chunk_spp=250, want_stats=False)
+    assert (bits(ctx.read_accum()) == bits(whole)).all()
+    _, st3 = ctx.render(cols, rows, 0, spp, 50, 1)                       # what bench.py launches
+    auto = ctx.read_accum()
+    assert st3["rays"] == st["rays"] and st3["term_depth"] == st["term_depth"]
+    np.testing.assert_allclose(auto, whole, rtol=2e-5, atol=1e-4)
+    assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() <= spp
+    fb_a, fb_w = ctx.resolve(spp), None
+    ctx.write_accum(cols, rows, whole)
+    fb_w = ctx.resolve(spp)
+    assert int(((fb_a ^ fb_w) != 0).sum()) < 100                         # 8-bit images agree but for a few rounding ties
+
+
+def test_config5_full_size_properties(ra, ctx, golden_scenes, monkeypatch):
+    """BASELINE configuration 5 at full size (20 164 spheres, 1200x800, 100 spp, depth 50): exact counters, and the streamed
+    table (default at this size) against per-wave reads of the table and against the VALU filter, bit for bit."""
+    cols, rows, spp = 1200, 800, 100
+    table = golden_scenes["scaled"]
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    _, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=4)
+    streamed = ctx.read_accum()
+    assert st["samples"] == cols * rows * spp and st["sphere_tests"] == st["rays"] * len(table)
+    assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
+    assert st["candidates"] < 3.0 * st["rays"]
+    monkeypatch.setenv("RTX_STREAM", "0")
+    _, st2 = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=4)
+    assert (bits(ctx.read_accum()) == bits(streamed)).all() and st2["rays"] == st["rays"]
+    monkeypatch.delenv("RTX_STREAM")
+    ctx.set_filter(ra.FILTER_VALU)
+    _, st3 = ctx.render(cols, rows, 0, 4, 50, 1, chunk_spp=4)            # the VALU filter is 6x slower here: one chunk of it
+    valu = ctx.read_accum()
+    ctx.set_filter(ra.FILTER_MFMA)
+    ctx.render(cols, rows, 0, 4, 50, 1, chunk_spp=4, want_stats=False)
+    assert (bits(ctx.read_accum()) == bits(valu)).all()
+
+
 @pytest.mark.parametrize("torch_first", [False, True])
 def test_one_hip_runtime_whichever_import_comes_first(torch_first):
     """torch bundles its own libamdhip64; librtx must share it, or a process that creates a context and THEN imports
