@@ -273,6 +273,24 @@ def test_config5_full_size_properties(ra, ctx, golden_scenes, monkeypatch):
     assert (bits(ctx.read_accum()) == bits(valu)).all()
 
 
+@pytest.mark.parametrize("scene,cols,rows,spp", [("book1", 3840, 2160, 32), ("glass", 1200, 800, 100)])
+def test_configs_3_and_4_full_frame(ra, ctx, golden_scenes, scene, cols, rows, spp):
+    """BASELINE configurations 3 (4K frame; 32 of its 4096 spp -- tools/c3_full.py runs them all) and 4 (glass-heavy, 100
+    spp): exact counters, repeatability, and additivity over a split of the sample range."""
+    ctx.upload_scene(golden_scenes[scene])
+    ctx.set_camera(ra.book_camera(cols, rows))
+    half = spp // 2
+    _, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=half)
+    whole = ctx.read_accum()
+    assert st["samples"] == cols * rows * spp and st["sphere_tests"] == st["rays"] * len(golden_scenes[scene])
+    assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
+    assert (2.6 < st["rays"] / st["samples"] < 2.8) if scene == "book1" else (2.9 < st["rays"] / st["samples"] < 3.2)
+    ctx.render(cols, rows, 0, half, 50, 1, chunk_spp=half, want_stats=False)
+    ctx.render(cols, rows, half, half, 50, 1, flags=ra.FLAG_ACCUMULATE, chunk_spp=half, want_stats=False)
+    assert (bits(ctx.read_accum()) == bits(whole)).all()
+    assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() <= spp
+
+
 @pytest.mark.parametrize("torch_first", [False, True])
 def test_one_hip_runtime_whichever_import_comes_first(torch_first):
     """torch bundles its own libamdhip64; librtx must share it, or a process that creates a context and THEN imports
