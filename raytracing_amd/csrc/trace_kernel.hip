@@ -340,10 +340,10 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 RTX_STAMP(10);
             };
             auto push_word = [&](uint32_t wv, uint32_t code) {
-                const uint64_t m = __ballot(wv != 0u);
+                const uint64_t m = __ballot(wv != 0u) & tmask;       // lanes without a ray carry stale operands: masked here
                 if (m) {
                     if (wq_count >= 64u) drain_words(64u);
-                    if (wv != 0u) wordq[(wq_head + wq_count + rank_in(m)) & 127u] = make_uint2(wv, (lane << 26) | code);
+                    if (wv != 0u && tracing) wordq[(wq_head + wq_count + rank_in(m)) & 127u] = make_uint2(wv, (lane << 26) | code);
                     wq_count += (uint32_t)__popcll(m);
                 }
             };
@@ -477,7 +477,6 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                         word[2u * w + 1u] = sw[1];
                     }
                     RTX_STAMP(2);
-                    if (!tracing) { word[0] = 0; word[1] = 0; word[2] = 0; word[3] = 0; }
                     // A queue entry is (group << 7) | (s << 5) | bit: word s = 2 w + hf' came from lane half hf' and tiles
                     // 2 w, 2 w + 1 of this 128-sphere group, and its bit b (from the LSB) was pushed p = 31 - b th: tile
                     // 2 w + (p >> 4), MFMA row 8 ((p >> 2) & 3) + 4 hf' + (p & 3).  The host lays the table out so that
