@@ -100,6 +100,20 @@ int rtx_upload_scene(rtx_ctx* ctx, uint32_t n,
  * default at rtx_create).  No counterpart in the reference: both forms feed the same exact sphere.cpp:68-102 test. */
 int rtx_set_filter(rtx_ctx* ctx, int kind);
 
+/* Tuning knobs of the launch (no counterpart in the reference; results do not depend on them except through the order
+ * in which a pixel's sample chunks are summed).  Each knob's initial value comes from the environment variable named
+ * beside it, read once at rtx_create.  Unknown keys and out-of-range values fail with RTX_ERR_ARG.
+ *   "block"          RTX_BLOCK           workgroup size, a multiple of 64 up to 512; 0 = automatic
+ *   "stream"         RTX_STREAM          stream the MFMA filter's table through the LDS stage: -1 automatic, 0 never, 1 always
+ *   "items_per_lane" RTX_ITEMS_PER_LANE  work items per lane that the smallest sample chunks are sized for (256)
+ *   "max_chunks"     RTX_MAX_CHUNKS      most sample chunks of an automatic plan (63)
+ *   "tail_factor"    RTX_TAIL_FACTOR     how many mean item durations the plan allows a single item to take (30)
+ *   "partials_mb"    RTX_PARTIALS_MB     cap of the partial-sum scratch (16 B per chunk and pixel) in MiB (1024)
+ *   "wave_batch"     RTX_WAVE_BATCH      work items a wave reserves per trip to the counter; 0 = automatic
+ *   "lds_pad"        RTX_LDS_PAD         extra LDS bytes per workgroup (experiments on occupancy)
+ *   "print_phases"   RTX_PRINT_PHASES    diagnostic builds only */
+int rtx_set_tuning(rtx_ctx* ctx, const char* key, int value);
+
 /* Replaces raytracer.cu:68-73 (_createCamera) / raytracerispc.cpp:91-103 (cameraInitISPC). */
 int rtx_set_camera(rtx_ctx* ctx, const rtx_camera* cam);
 
@@ -116,6 +130,13 @@ int rtx_set_camera(rtx_ctx* ctx, const rtx_camera* cam);
  *   stats      : NULL or counters of this call */
 int rtx_render(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
                uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint32_t* primary_hit_host, rtx_stats* stats);
+
+/* The sample chunks of the most recent rtx_render / rtx_render_async (no counterpart in the reference): a pixel's samples
+ * are summed per chunk, in sample order, and the chunk sums are added in chunk order.  *chunk_spp receives the uniform chunk
+ * size when the caller chose one; otherwise it receives 0, *n_chunks the number of chunks of the automatic plan (large
+ * chunks first, small ones last) and starts[0 .. *n_chunks] their boundaries relative to spp_begin (`cap` entries are
+ * available; 64 always suffice).  A CPU restatement summing in that same order reproduces an automatic launch bit for bit. */
+int rtx_last_chunk_plan(rtx_ctx* ctx, uint32_t* chunk_spp, uint32_t* n_chunks, uint32_t* starts, uint32_t cap);
 
 /* Same, but only enqueues the work on the context's stream and returns; rtx_sync() waits.  bench.py brackets
  * K of these with one rtx_sync.  Statistics and primary-hit maps are not available in this form. */
@@ -167,6 +188,13 @@ uint32_t rtx_scene_capacity(int grid_half);
 int rtx_random_scene(uint64_t seed, int grid_half, float p_diffuse, float p_metal, uint32_t* n,
                      float* cx, float* cy, float* cz, float* radius, uint32_t* mat_type,
                      float* albedo_r, float* albedo_g, float* albedo_b, float* blur, float* ior);
+
+/* The automatic sample-chunk plan of rtx_render as a pure function (no GPU, no counterpart in the reference): fills
+ * starts[0 .. *n_chunks] (cap >= 64) for `spp_count` samples of `n_pixels` pixels traced by `lanes` resident lanes, with
+ * the knobs of rtx_set_tuning and at most max_items = chunks * pixels work items.  Large chunks come first and shrink
+ * geometrically to the size that gives every lane `items_per_lane` items: only the END of a launch needs small items. */
+int rtx_plan_chunks(uint32_t spp_count, uint64_t n_pixels, uint64_t lanes, uint32_t items_per_lane, uint32_t max_chunks,
+                    uint32_t tail_factor, uint64_t max_items, uint32_t* starts, uint32_t cap, uint32_t* n_chunks);
 
 /* RayTracing.cpp:152-165: "P3\n<cols> <rows>\n255\n" then "r g b\n" per pixel. */
 int rtx_write_ppm(const char* path, uint32_t cols, uint32_t rows, const uint32_t* framebuffer_host);

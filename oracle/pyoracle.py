@@ -99,6 +99,9 @@ def lib():
         L.ro_render.restype = C.c_int
         L.ro_render.argtypes = [P(Sphere), C.c_uint32, P(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, P(C.c_float), P(C.c_uint32), P(Stats)]
+        L.ro_render_plan.restype = C.c_int
+        L.ro_render_plan.argtypes = [P(Sphere), C.c_uint32, P(Camera), C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_uint32), C.c_uint32,
+                                     C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, P(C.c_float), P(C.c_uint32), P(Stats)]
         L.ro_resolve.argtypes = [P(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_uint32)]
         L.ro_random_scene_capacity.restype = C.c_uint32
         L.ro_random_scene_capacity.argtypes = [C.c_int]
@@ -175,8 +178,9 @@ def camera_from_array(a):
 
 
 def render(table, cam, rows, cols, spp_begin, spp_count, max_depth, seed, chunk_spp=0, recursive=False,
-           nthreads=None, tile=64, want_primary=False):
-    """Returns (accum[rows*cols*3] float32, primary or None, stats dict)."""
+           nthreads=None, tile=64, want_primary=False, chunk_starts=None):
+    """Returns (accum[rows*cols*3] float32, primary or None, stats dict).  chunk_starts: explicit chunk boundaries
+    (relative to spp_begin, first 0, last spp_count) instead of the uniform chunk_spp."""
     L = lib()
     sph = table_to_spheres(table)
     accum = np.zeros(rows * cols * 3, dtype=np.float32)
@@ -184,9 +188,16 @@ def render(table, cam, rows, cols, spp_begin, spp_count, max_depth, seed, chunk_
     st = Stats()
     if nthreads is None:
         nthreads = min(8, os.cpu_count() or 1)
-    rc = L.ro_render(sph, len(table), C.byref(cam), rows, cols, spp_begin, spp_count, chunk_spp, max_depth, seed,
-                     1 if recursive else 0, nthreads, tile, accum.ctypes.data_as(C.POINTER(C.c_float)),
-                     primary.ctypes.data_as(C.POINTER(C.c_uint32)) if want_primary else None, C.byref(st))
+    if chunk_starts is not None:
+        cs = np.ascontiguousarray(chunk_starts, dtype=np.uint32)
+        assert cs[0] == 0 and cs[-1] == spp_count
+        rc = L.ro_render_plan(sph, len(table), C.byref(cam), rows, cols, spp_begin, cs.ctypes.data_as(C.POINTER(C.c_uint32)), len(cs) - 1,
+                              max_depth, seed, 1 if recursive else 0, nthreads, tile, accum.ctypes.data_as(C.POINTER(C.c_float)),
+                              primary.ctypes.data_as(C.POINTER(C.c_uint32)) if want_primary else None, C.byref(st))
+    else:
+        rc = L.ro_render(sph, len(table), C.byref(cam), rows, cols, spp_begin, spp_count, chunk_spp, max_depth, seed,
+                         1 if recursive else 0, nthreads, tile, accum.ctypes.data_as(C.POINTER(C.c_float)),
+                         primary.ctypes.data_as(C.POINTER(C.c_uint32)) if want_primary else None, C.byref(st))
     if rc != 0:
         raise RuntimeError("ro_render failed")
     return accum, primary, st.as_dict()

@@ -404,31 +404,49 @@ ro_vec3 ro_color_recursive(const ro_ray* r, const ro_sphere* scene, uint32_t n, 
 
 /* ---- raytracer.cpp:175-186 ------------------------------------------------------------------------------------ */
 
+/* One chunk: samples [c0, c1) of the range, added in index order (color += ..., vector_cuda.h:147-153). */
+static ro_vec3 chunk_sum(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols, uint32_t x, uint32_t y,
+                         uint32_t spp_begin, uint32_t c0, uint32_t c1, uint32_t max_depth, uint64_t seed, int recursive,
+                         uint32_t* primary_hit, uint32_t primary_stride, ro_stats* st)
+{
+    ro_vec3  color = v3(0, 0, 0);
+    uint32_t pixel = y * cols + x;
+    for (uint32_t k = c0; k < c1; ++k) {
+        ro_rng g;
+        ro_rng_begin_sample(&g, seed, pixel, spp_begin + k);
+        float    u = (float)(x + ro_random(&g)) / (float)cols;   /* uint + float -> float, raytracer.cpp:177 */
+        float    v = (float)(y + ro_random(&g)) / (float)rows;
+        ro_ray   r = ro_camera_get_ray(cam, u, v, &g);
+        uint32_t first;
+        ro_vec3  c = recursive ? ro_color_recursive(&r, scene, n, 0, max_depth, &g, &first, st)
+                               : ro_color(&r, scene, n, max_depth, &g, &first, st);
+        color = v_add(color, c);
+        if (primary_hit) primary_hit[(size_t)k * primary_stride] = first;
+        if (st) st->samples++;
+    }
+    return color;
+}
+
 ro_vec3 ro_pixel_sum(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
                      uint32_t x, uint32_t y, uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp,
                      uint32_t max_depth, uint64_t seed, int recursive, uint32_t* primary_hit, uint32_t primary_stride, ro_stats* st)
 {
-    ro_vec3  total = v3(0, 0, 0);
-    uint32_t pixel = y * cols + x;
+    ro_vec3 total = v3(0, 0, 0);
     if (chunk_spp == 0 || chunk_spp > spp_count) chunk_spp = spp_count;
     for (uint32_t c0 = 0; c0 < spp_count; c0 += chunk_spp) {
-        uint32_t c1    = (c0 + chunk_spp < spp_count) ? c0 + chunk_spp : spp_count;
-        ro_vec3  color = v3(0, 0, 0);
-        for (uint32_t k = c0; k < c1; ++k) {
-            ro_rng g;
-            ro_rng_begin_sample(&g, seed, pixel, spp_begin + k);
-            float    u = (float)(x + ro_random(&g)) / (float)cols;   /* uint + float -> float, raytracer.cpp:177 */
-            float    v = (float)(y + ro_random(&g)) / (float)rows;
-            ro_ray   r = ro_camera_get_ray(cam, u, v, &g);
-            uint32_t first;
-            ro_vec3  c = recursive ? ro_color_recursive(&r, scene, n, 0, max_depth, &g, &first, st)
-                                   : ro_color(&r, scene, n, max_depth, &g, &first, st);
-            color = v_add(color, c);                               /* color += ..., vector_cuda.h:147-153 */
-            if (primary_hit) primary_hit[(size_t)k * primary_stride] = first;
-            if (st) st->samples++;
-        }
-        total = v_add(total, color);
+        uint32_t c1 = (c0 + chunk_spp < spp_count) ? c0 + chunk_spp : spp_count;
+        total = v_add(total, chunk_sum(scene, n, cam, rows, cols, x, y, spp_begin, c0, c1, max_depth, seed, recursive, primary_hit, primary_stride, st));
     }
+    return total;
+}
+
+ro_vec3 ro_pixel_sum_plan(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+                          uint32_t x, uint32_t y, uint32_t spp_begin, const uint32_t* starts, uint32_t nchunks,
+                          uint32_t max_depth, uint64_t seed, int recursive, uint32_t* primary_hit, uint32_t primary_stride, ro_stats* st)
+{
+    ro_vec3 total = v3(0, 0, 0);
+    for (uint32_t k = 0; k < nchunks; ++k)
+        total = v_add(total, chunk_sum(scene, n, cam, rows, cols, x, y, spp_begin, starts[k], starts[k + 1], max_depth, seed, recursive, primary_hit, primary_stride, st));
     return total;
 }
 
@@ -437,6 +455,7 @@ ro_vec3 ro_pixel_sum(const ro_sphere* scene, uint32_t n, const ro_camera* cam, u
 typedef struct {
     const ro_sphere* scene; uint32_t n; const ro_camera* cam; uint32_t rows, cols, spp_begin, spp_count, chunk_spp, max_depth;
     uint64_t seed; int recursive; uint32_t tile, tiles_x, tiles_y; float* accum; uint32_t* primary;
+    const uint32_t* starts; uint32_t nchunks;          /* ro_render_plan: explicit chunk boundaries instead of chunk_spp */
     volatile uint32_t next_tile; pthread_mutex_t lock; ro_stats stats;
 } render_job;
 
@@ -453,8 +472,11 @@ static void* render_worker(void* arg)
             for (uint32_t x = x0; x < x0 + j->tile && x < j->cols; ++x) {
                 size_t    p  = (size_t)y * j->cols + x;
                 uint32_t* ph = j->primary ? j->primary + p : NULL;
-                ro_vec3   c  = ro_pixel_sum(j->scene, j->n, j->cam, j->rows, j->cols, x, y, j->spp_begin, j->spp_count, j->chunk_spp,
-                                            j->max_depth, j->seed, j->recursive, ph, j->rows * j->cols, &st);
+                ro_vec3   c  = j->starts
+                    ? ro_pixel_sum_plan(j->scene, j->n, j->cam, j->rows, j->cols, x, y, j->spp_begin, j->starts, j->nchunks,
+                                        j->max_depth, j->seed, j->recursive, ph, j->rows * j->cols, &st)
+                    : ro_pixel_sum(j->scene, j->n, j->cam, j->rows, j->cols, x, y, j->spp_begin, j->spp_count, j->chunk_spp,
+                                   j->max_depth, j->seed, j->recursive, ph, j->rows * j->cols, &st);
                 j->accum[3 * p + 0] = c.x;
                 j->accum[3 * p + 1] = c.y;
                 j->accum[3 * p + 2] = c.z;
@@ -468,9 +490,10 @@ static void* render_worker(void* arg)
     return NULL;
 }
 
-int ro_render(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
-              uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp, uint32_t max_depth, uint64_t seed,
-              int recursive, uint32_t nthreads, uint32_t tile, float* accum_rgb, uint32_t* primary_hit, ro_stats* st)
+static int render_frame(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+                        uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp, const uint32_t* starts, uint32_t nchunks,
+                        uint32_t max_depth, uint64_t seed, int recursive, uint32_t nthreads, uint32_t tile, float* accum_rgb,
+                        uint32_t* primary_hit, ro_stats* st)
 {
     render_job j;
     memset(&j, 0, sizeof(j));
@@ -478,6 +501,7 @@ int ro_render(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t
     if (nthreads == 0) nthreads = 1;
     j.scene = scene; j.n = n; j.cam = cam; j.rows = rows; j.cols = cols; j.spp_begin = spp_begin; j.spp_count = spp_count;
     j.chunk_spp = chunk_spp; j.max_depth = max_depth; j.seed = seed; j.recursive = recursive; j.tile = tile;
+    j.starts = starts; j.nchunks = nchunks;
     j.tiles_x = (cols + tile - 1) / tile; j.tiles_y = (rows + tile - 1) / tile; j.accum = accum_rgb; j.primary = primary_hit;
     pthread_mutex_init(&j.lock, NULL);
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
@@ -489,6 +513,22 @@ int ro_render(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t
     pthread_mutex_destroy(&j.lock);
     if (st) *st = j.stats;
     return 0;
+}
+
+int ro_render(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+              uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp, uint32_t max_depth, uint64_t seed,
+              int recursive, uint32_t nthreads, uint32_t tile, float* accum_rgb, uint32_t* primary_hit, ro_stats* st)
+{
+    return render_frame(scene, n, cam, rows, cols, spp_begin, spp_count, chunk_spp, NULL, 0, max_depth, seed, recursive, nthreads, tile, accum_rgb, primary_hit, st);
+}
+
+int ro_render_plan(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+                   uint32_t spp_begin, const uint32_t* starts, uint32_t nchunks, uint32_t max_depth, uint64_t seed,
+                   int recursive, uint32_t nthreads, uint32_t tile, float* accum_rgb, uint32_t* primary_hit, ro_stats* st)
+{
+    if (!starts || nchunks == 0 || starts[0] != 0) return -1;
+    for (uint32_t k = 0; k < nchunks; ++k) if (starts[k + 1] < starts[k]) return -1;
+    return render_frame(scene, n, cam, rows, cols, spp_begin, starts[nchunks], 0, starts, nchunks, max_depth, seed, recursive, nthreads, tile, accum_rgb, primary_hit, st);
 }
 
 /* ---- raytracer.cpp:187-197 (+ :168-171 for -d) -------------------------------------------------------------------- */

@@ -99,12 +99,23 @@ ro_vec3 ro_pixel_sum(const ro_sphere* scene, uint32_t n, const ro_camera* cam, u
                      uint32_t x, uint32_t y, uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp,
                      uint32_t max_depth, uint64_t seed, int recursive, uint32_t* primary_hit, uint32_t primary_stride, ro_stats* st);
 
+/* The same with explicit chunk boundaries: chunk k covers samples [starts[k], starts[k+1]) of the range, starts[0] = 0
+ * (the GPU backend's automatic plan: large chunks first, small ones last -- rtx_last_chunk_plan). */
+ro_vec3 ro_pixel_sum_plan(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+                          uint32_t x, uint32_t y, uint32_t spp_begin, const uint32_t* starts, uint32_t nchunks,
+                          uint32_t max_depth, uint64_t seed, int recursive, uint32_t* primary_hit, uint32_t primary_stride, ro_stats* st);
+
 /* Whole frame, nthreads worker threads pulling tile x tile pixel blocks from a shared counter (the role of
  * thread_pool.cpp + raytracer.cpp:93-127).  accum_rgb: rows*cols*3 floats, the un-normalised colour sums.
  * primary_hit (may be NULL): spp_count*rows*cols entries, [(s-spp_begin)*rows*cols + y*cols + x]. */
 int ro_render(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
               uint32_t spp_begin, uint32_t spp_count, uint32_t chunk_spp, uint32_t max_depth, uint64_t seed,
               int recursive, uint32_t nthreads, uint32_t tile, float* accum_rgb, uint32_t* primary_hit, ro_stats* st);
+
+/* ro_render with the explicit chunk boundaries of ro_pixel_sum_plan; the sample count is starts[nchunks]. */
+int ro_render_plan(const ro_sphere* scene, uint32_t n, const ro_camera* cam, uint32_t rows, uint32_t cols,
+                   uint32_t spp_begin, const uint32_t* starts, uint32_t nchunks, uint32_t max_depth, uint64_t seed,
+                   int recursive, uint32_t nthreads, uint32_t tile, float* accum_rgb, uint32_t* primary_hit, ro_stats* st);
 
 /* raytracer.cpp:187-197: /= spp, sqrt, (uint8_t)(255.99 * c) in double, pack R<<24|G<<16|B<<8.
  * debug_tile != 0 reproduces -d (raytracer.cpp:168-171): pixels on tile borders become 0xFF000000. */

@@ -7,8 +7,8 @@ material.h, camera.h).  There is no CPU fallback: without the built library, or 
 raises.
 """
 from .api import (Camera, Context, Material, RtxError, Scene, Sphere, Stats, book_camera, lib, random_scene,
-                  render_scene_hip, write_ppm, MATERIAL_DIFFUSE, MATERIAL_GLASS, MATERIAL_METAL, FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER,
+                  render_scene_hip, write_ppm, plan_chunks, MATERIAL_DIFFUSE, MATERIAL_GLASS, MATERIAL_METAL, FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER,
                   FILTER_MFMA, FILTER_VALU)
 
 __all__ = ["Camera", "Context", "Material", "RtxError", "Scene", "Sphere", "Stats", "book_camera", "lib", "random_scene",
-           "render_scene_hip", "write_ppm", "MATERIAL_DIFFUSE", "MATERIAL_GLASS", "MATERIAL_METAL", "FLAG_ACCUMULATE", "FLAG_RECURSIVE", "FLAG_VALIDATE_FILTER", "FILTER_MFMA", "FILTER_VALU"]
+           "render_scene_hip", "write_ppm", "plan_chunks", "MATERIAL_DIFFUSE", "MATERIAL_GLASS", "MATERIAL_METAL", "FLAG_ACCUMULATE", "FLAG_RECURSIVE", "FLAG_VALIDATE_FILTER", "FILTER_MFMA", "FILTER_VALU"]

@@ -15,9 +15,9 @@ FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER = 1, 2, 4
 FILTER_VALU, FILTER_MFMA = 0, 1
 
 # every symbol include/rtx.h declares
-EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_camera", "rtx_render",
+EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_set_camera", "rtx_render",
            "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
-           "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6",
+           "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks",
            "rtx_version"]
 
 
@@ -82,6 +82,8 @@ def lib():
     L.rtx_destroy.argtypes = [C.c_void_p]
     L.rtx_upload_scene.argtypes = [C.c_void_p, u32, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
     L.rtx_set_filter.argtypes = [C.c_void_p, C.c_int]
+    L.rtx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.rtx_last_chunk_plan.argtypes = [C.c_void_p, up, up, up, u32]
     L.rtx_set_camera.argtypes = [C.c_void_p, P(CCamera)]
     L.rtx_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, up, P(Stats)]
     L.rtx_render_async.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32]
@@ -97,6 +99,7 @@ def lib():
     L.rtx_scene_capacity.restype = u32
     L.rtx_scene_capacity.argtypes = [C.c_int]
     L.rtx_random_scene.argtypes = [u64, C.c_int, f32, f32, up, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
+    L.rtx_plan_chunks.argtypes = [u32, u64, u64, u32, u32, u32, u64, up, u32, up]
     L.rtx_write_ppm.argtypes = [C.c_char_p, u32, u32, up]
     L.rtx_write_ppm_p6.argtypes = [C.c_char_p, u32, u32, up]
     L.rtx_save_accum.argtypes = [C.c_void_p, C.c_char_p, u32, u64, u32, u32]
@@ -188,6 +191,14 @@ def random_scene(seed=1, grid_half=11, p_diffuse=0.8, p_metal=0.95):
     return np.stack([f[0][:n], f[1][:n], f[2][:n], f[3][:n], t[:n].astype(np.float32), f[4][:n], f[5][:n], f[6][:n], f[7][:n], f[8][:n]], axis=1)
 
 
+def plan_chunks(spp_count, n_pixels, lanes, items_per_lane=256, max_chunks=63, tail_factor=30, max_items=1 << 26):
+    """The automatic sample-chunk plan (rtx_plan_chunks): boundaries relative to spp_begin, first 0, last spp_count."""
+    starts = np.zeros(64, dtype=np.uint32)
+    n = C.c_uint32(0)
+    _check(lib().rtx_plan_chunks(spp_count, n_pixels, lanes, items_per_lane, max_chunks, tail_factor, max_items, _up(starts), 64, C.byref(n)))
+    return starts[:n.value + 1].copy()
+
+
 def write_ppm(path, cols, rows, framebuffer, binary=False):
     """RayTracing.cpp:152-165 ("P3" text); binary=True writes the same pixels as "P6"."""
     fb = np.ascontiguousarray(framebuffer, dtype=np.uint32)
@@ -226,6 +237,17 @@ class Context:
 
     def set_filter(self, kind):
         _check(lib().rtx_set_filter(self._h, kind))
+
+    def set_tuning(self, key, value):
+        """A launch knob of include/rtx.h (rtx_set_tuning): "block", "stream", "max_chunks", ..."""
+        _check(lib().rtx_set_tuning(self._h, key.encode(), int(value)))
+
+    def last_chunk_plan(self):
+        """(chunk_spp, None) for uniform chunks, or (0, boundaries) of the automatic plan of the most recent render."""
+        cs, n = C.c_uint32(), C.c_uint32()
+        starts = np.zeros(64, dtype=np.uint32)
+        _check(lib().rtx_last_chunk_plan(self._h, C.byref(cs), C.byref(n), _up(starts), 64))
+        return (cs.value, None) if cs.value else (0, starts[:n.value + 1].copy())
 
     def set_camera(self, cam):
         c = cam.c if isinstance(cam, Camera) else cam

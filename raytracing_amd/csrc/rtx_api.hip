@@ -31,6 +31,28 @@ static int fail(int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Tuning knobs (rtx_set_tuning; the RTX_* environment variables give their initial values, read ONCE at rtx_create).
+struct Tuning {
+    int block = 0;              // forced workgroup size (0: the size that keeps the most waves resident)
+    int stream = -1;            // table streaming through the LDS stage: -1 automatic, 0 never, 1 always (MFMA filter)
+    int lds_pad = 0;            // extra LDS bytes per workgroup (lowers the occupancy; experiments)
+    int items_per_lane = 256;   // work items per lane that the smallest chunks are sized for
+    int max_chunks = (int)kMaxPlanChunks;
+    int wave_batch = 0;         // forced reservation size (0: automatic)
+    int tail_factor = 30;       // how many mean item durations a single item may take (heavy-tailed pixels), see plan_chunks
+    int partials_mb = 1024;     // cap of the partial-sum scratch in MiB
+    int print_phases = 0;
+};
+
+// Launch geometry of one (filter, scene) pair: worked out once per scene, not per launch.
+struct LaunchPlan {
+    bool     valid = false;
+    int      table_mode = kTableGlobal;
+    uint32_t block = 0;
+    size_t   lds_bytes = 0;
+    uint32_t max_grid = 0;
+};
+
 struct rtx_ctx {
     int         device = -1;
     int         num_cu = 0;
@@ -44,7 +66,7 @@ struct rtx_ctx {
     int      filter = kFilterMfma;
     bool     mfma_ok = false;       // the scene fits the f16 range of the MFMA filter
     float    mfma_scale = 1.0f;
-    double   mfma_omax = 0.0;       // largest |component| of a ray origin the MFMA filter's f16 operands can carry
+    double   mfma_omax = 0.0;       // largest |o| (norm) of a ray origin the MFMA filter's f16 operands can carry
     float4*  hot = nullptr;
     float4*  hot_mfma = nullptr;
     float4*  exact = nullptr;
@@ -61,6 +83,11 @@ struct rtx_ctx {
     uint32_t* fb = nullptr; size_t fb_items = 0;
     uint32_t* work_counter = nullptr;
     unsigned long long* stats = nullptr;
+    Tuning     tune;
+    LaunchPlan plan[2];            // by effective filter
+    uint32_t   last_tab[kMaxPlanChunks + 1] = { 0 };   // chunk boundaries of the most recent launch (rtx_last_chunk_plan)
+    uint32_t   last_nchunks = 0, last_chunk_spp = 0;
+    unsigned char* scratch = nullptr;                  // this device's copy of the static scratch array (rtx_render_noalloc)
 };
 
 extern "C" const char* rtx_last_error(void) { return g_last_error.c_str(); }
@@ -81,7 +108,14 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     if (!c) return fail(RTX_ERR_NOMEM, "rtx_create: out of host memory");
     c->device = device_id;
     c->num_cu = prop.multiProcessorCount;
+    // the environment is read here and nowhere else; rtx_set_filter / rtx_set_tuning change the values afterwards
     if (const char* f = getenv("RTX_FILTER")) c->filter = (strcmp(f, "valu") == 0) ? kFilterValu : kFilterMfma;
+    static const struct { const char* env; const char* key; } kEnv[] = {
+        { "RTX_BLOCK", "block" }, { "RTX_STREAM", "stream" }, { "RTX_LDS_PAD", "lds_pad" }, { "RTX_ITEMS_PER_LANE", "items_per_lane" },
+        { "RTX_MAX_CHUNKS", "max_chunks" }, { "RTX_WAVE_BATCH", "wave_batch" }, { "RTX_TAIL_FACTOR", "tail_factor" },
+        { "RTX_PARTIALS_MB", "partials_mb" }, { "RTX_PRINT_PHASES", "print_phases" } };
+    for (const auto& kv : kEnv)
+        if (const char* v = getenv(kv.env)) (void)rtx_set_tuning(c, kv.key, atoi(v));     // out-of-range values are ignored, as before
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_first);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_last);
@@ -144,21 +178,25 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     // power of two that keeps all of these, and 2 scale (|C| + r) for any bounce origin, inside the f16 range; the camera
     // origin is checked against the same bound per launch (else the VALU filter runs).
     const uint32_t n_pad_mfma = (n + 127u) & ~127u;
-    double max_c = 0.0, max_o = 0.0, max_k = 0.0;
+    // Range guard: every f16 operand of the filter is bounded by the NORM of a ray origin -- 2 sg C_i and sg (o.d' d'_i - o_i)
+    // (the part of o perpendicular to d') by sg |o|, the per-ray constant sg^2 2^-15 (|o|^2' - (o.d')^2) by sg^2 2^-15 |o|^2 -- and
+    // a bounce origin lies on a sphere, |o| <= |C| + r.  sg (|C| + 1.01 r) <= 30000 keeps all of them finite in f16
+    // (30000^2 2^-15 = 27466); the camera's lens is checked against the same bound per launch.
+    double max_on = 0.0, max_k = 0.0;
     bool   finite = true;
     for (uint32_t i = 0; i < n; ++i) {
         const double comp[3] = { std::fabs((double)cx[i]), std::fabs((double)cy[i]), std::fabs((double)cz[i]) };
         const double r = std::fabs((double)radius[i]);
         finite = finite && std::isfinite(comp[0]) && std::isfinite(comp[1]) && std::isfinite(comp[2]) && std::isfinite(r);
         const double C2 = comp[0] * comp[0] + comp[1] * comp[1] + comp[2] * comp[2], r2 = r * r;
-        for (double v : comp) { max_c = std::max(max_c, v); max_o = std::max(max_o, v + 1.01 * r); }
-        max_k = std::max(max_k, (1.0 + 3.0 * kGammaSphere) * (C2 + r2));
+        max_on = std::max(max_on, std::sqrt(C2) + 1.01 * r);
+        max_k  = std::max(max_k, (1.0 + 3.0 * kGammaSphere) * (C2 + r2));
     }
     int exp2 = 40;
     if (finite && n > 0) {
         while (exp2 > -40) {
             const double sgm = std::ldexp(1.0, exp2);
-            if (2.0 * sgm * max_c <= 60000.0 && 2.0 * sgm * max_o <= 60000.0 && sgm * sgm * max_k * std::ldexp(1.0, -15) + 1.0 <= 60000.0) break;
+            if (sgm * max_on <= 30000.0 && sgm * sgm * max_k * std::ldexp(1.0, -15) + 1.0 <= 60000.0) break;
             --exp2;
         }
     } else {
@@ -224,7 +262,29 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     HIP_TRY(hipMemcpy(c->exact, exact.data(), exact.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat, mat.data(), mat.size() * sizeof(uint4), hipMemcpyHostToDevice));
     c->n = n; c->n_pad = n_pad; c->n_pad_mfma = n_pad_mfma; c->have_scene = true;
+    c->plan[0].valid = c->plan[1].valid = false;
     c->mfma_ok = mfma_ok; c->mfma_scale = (float)sgm; c->mfma_omax = 30000.0 / sgm;
+    return RTX_OK;
+}
+
+extern "C" int rtx_set_tuning(rtx_ctx* c, const char* key, int value)
+{
+    if (!c || !key) return fail(RTX_ERR_ARG, "rtx_set_tuning: NULL argument");
+    Tuning& t = c->tune;
+    const std::string k = key;
+    bool ok = true;
+    if (k == "block")               { ok = value == 0 || (value >= 64 && value <= (int)kMaxBlock && value % 64 == 0); if (ok) t.block = value; }
+    else if (k == "stream")         { ok = value >= -1 && value <= 1; if (ok) t.stream = value; }
+    else if (k == "lds_pad")        { ok = value >= 0 && value <= 160 * 1024; if (ok) t.lds_pad = value; }
+    else if (k == "items_per_lane") { ok = value >= 1; if (ok) t.items_per_lane = value; }
+    else if (k == "max_chunks")     { ok = value >= 1; if (ok) t.max_chunks = std::min<int>(value, (int)kMaxPlanChunks); }
+    else if (k == "wave_batch")     { ok = value == 0 || (value >= 64 && value <= 4096); if (ok) t.wave_batch = value; }
+    else if (k == "tail_factor")    { ok = value >= 1 && value <= 1024; if (ok) t.tail_factor = value; }
+    else if (k == "partials_mb")    { ok = value >= 1; if (ok) t.partials_mb = value; }
+    else if (k == "print_phases")   { t.print_phases = value != 0; }
+    else return fail(RTX_ERR_ARG, "rtx_set_tuning: unknown knob '%s'", key);
+    if (!ok) return fail(RTX_ERR_ARG, "rtx_set_tuning: value %d is out of range for '%s'", value, key);
+    c->plan[0].valid = c->plan[1].valid = false;
     return RTX_OK;
 }
 
@@ -255,64 +315,24 @@ template <typename T> static int ensure(T** buf, size_t* have, size_t want)
     return RTX_OK;
 }
 
-static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
-                          uint64_t seed, uint32_t flags, uint32_t chunk_spp, bool want_primary, bool want_stats)
+// Table placement and workgroup size of a (filter, scene) pair: the MFMA filter's table is staged into LDS only while that
+// does not cost resident waves -- an L2-fed table with 4 waves/SIMD beats an LDS-resident one with 2 (677 spheres: 17.5
+// against 20.9 ms per 100 spp; with equal occupancy LDS wins by 7 %).  The group size is the one that keeps the most waves
+// resident (the LDS table is per workgroup, so a larger group amortises it over more waves).  A large table that is not
+// LDS-resident is, for the MFMA filter, streamed through a small LDS stage that the waves of a workgroup fill together
+// (one L2 read per workgroup instead of one per wave).  The price is a barrier per 128 spheres, i.e. waves in lockstep:
+// measured +8 % at 20 164 spheres, +4 % at 4 901, -4 % at 1 601 (profiles/r01h_*), hence the threshold.
+static const LaunchPlan& launch_plan(rtx_ctx* c, int filter)
 {
-    if (!c) return fail(RTX_ERR_ARG, "rtx_render: ctx is NULL");
-    if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "rtx_render: upload a scene and a camera first");
-    if (cols == 0 || rows == 0 || spp_count == 0) return fail(RTX_ERR_ARG, "rtx_render: cols, rows and spp_count must be non-zero");
-    if ((uint64_t)cols * rows > (1ull << 28)) return fail(RTX_ERR_ARG, "rtx_render: image of %u x %u exceeds 2^28 pixels", cols, rows);
-    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_ARG, "rtx_render: sample range overflows 32 bits");
-    if (flags & ~(uint32_t)(RTX_FLAG_ACCUMULATE | RTX_FLAG_RECURSIVE | RTX_FLAG_VALIDATE_FILTER)) return fail(RTX_ERR_ARG, "rtx_render: unknown flag bits 0x%x", flags);
-    HIP_TRY(hipSetDevice(c->device));
-
-    const uint32_t npix = cols * rows;
-    const bool     accumulate = (flags & RTX_FLAG_ACCUMULATE) != 0;
-    if (accumulate && (c->cols != cols || c->rows != rows || !c->accum)) return fail(RTX_ERR_STATE, "rtx_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
-    if (c->cols != cols || c->rows != rows) { HIP_TRY(hipStreamSynchronize(c->stream)); }
-    int rc = RTX_OK;
-    if (c->accum_borrowed) {
-        if (c->accum_floats != (size_t)npix * 3) return fail(RTX_ERR_STATE, "rtx_render: the caller's accumulation buffer holds %zu floats, this image needs %zu", c->accum_floats, (size_t)npix * 3);
-    } else {
-        rc = ensure(&c->accum, &c->accum_floats, (size_t)npix * 3);
-        if (rc) return rc;
-    }
-    c->cols = cols; c->rows = rows;
-
-    if (!c->ev_open) { HIP_TRY(hipEventRecord(c->ev_first, c->stream)); c->ev_open = true; }
-
-    if (max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE)) {
-        // raytracer.cpp:250: the bounce loop does not run, _color returns (1,1,1) for every sample (-r still traces the primary ray)
-        launch_fill(c->accum, npix * 3, (float)spp_count, accumulate, c->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_last, c->stream));
-        if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
-        return RTX_OK;
-    }
-
-    const bool   validate  = (flags & RTX_FLAG_VALIDATE_FILTER) != 0;
-    int          filter    = c->filter;
-    if (filter == kFilterMfma) {
-        // primary rays start on the lens (camera.h:75-86); bounce rays start on spheres, which the scale already covers
-        bool fits = c->mfma_ok;
-        for (int k = 0; k < 3 && fits; ++k) {
-            const double reach = std::fabs((double)c->cam.origin[k]) + std::fabs((double)c->cam.lens_radius) * (std::fabs((double)c->cam.u[k]) + std::fabs((double)c->cam.v[k]));
-            fits = std::isfinite(reach) && reach <= c->mfma_omax;
-        }
-        if (!fits) filter = kFilterValu;
-    }
-    // Table placement and workgroup size: the MFMA filter's table is staged into LDS only while that does not cost resident waves --
-    // an L2-fed table with 4 waves/SIMD beats an LDS-resident one with 2 (677 spheres: 17.5 against 20.9 ms per 100 spp;
-    // with equal occupancy LDS wins by 7 %).  The group size is the one that keeps the most waves resident (the LDS table
-    // is per workgroup, so a larger group amortises it over more waves).  RTX_BLOCK overrides the group size.
+    LaunchPlan& lp = c->plan[filter];
+    if (lp.valid) return lp;
+    const Tuning& t = c->tune;
     const bool lds_fits = (filter == kFilterMfma) ? c->n_pad_mfma <= kMaxLdsSpheresMfma : c->n_pad <= kMaxLdsSpheres;
-    uint32_t forced = 0u;
-    if (const char* b = getenv("RTX_BLOCK")) { int v = atoi(b); if (v >= 64 && v <= (int)kMaxBlock && v % 64 == 0) forced = (uint32_t)v; }
     auto best_block = [&](int mode, uint32_t* waves_out) -> uint32_t {
         uint32_t best = 0u, best_waves = 0u;
         for (uint32_t cand : { 512u, 256u }) {
-            if (forced && cand != 512u) break;
-            const uint32_t blk = forced ? forced : cand;
+            if (t.block && cand != 512u) break;
+            const uint32_t blk = t.block ? (uint32_t)t.block : cand;
             const size_t lb = trace_lds_bytes(filter, mode, c->n, c->n_pad, c->n_pad_mfma, blk);
             const uint32_t waves = (uint32_t)trace_occupancy(filter, mode, lb, blk) * (blk / 64u);
             if (waves > best_waves) { best_waves = waves; best = blk; }
@@ -320,88 +340,186 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         *waves_out = best_waves;
         return best;
     };
-    // A large table that is not LDS-resident is, for the MFMA filter, streamed through a small LDS stage that the waves of
-    // a workgroup fill together (one L2 read per workgroup instead of one per wave).  The price is a barrier per 128
-    // spheres, i.e. waves in lockstep: measured +8 % at 20 164 spheres, +4 % at 4 901, -4 % at 1 601
-    // (profiles/r01h_*), hence the threshold.  RTX_STREAM=1 / 0 forces it on / off.
     bool stream_ok = filter == kFilterMfma && c->n_pad_mfma >= 3072u;
-    if (const char* e = getenv("RTX_STREAM")) stream_ok = filter == kFilterMfma && atoi(e) != 0;
-    const int  far_mode  = stream_ok ? kTableStream : kTableGlobal;
+    if (t.stream >= 0) stream_ok = filter == kFilterMfma && t.stream != 0;
+    const int far_mode = stream_ok ? kTableStream : kTableGlobal;
     uint32_t waves_global = 0u, waves_lds = 0u;
-    uint32_t block = best_block(far_mode, &waves_global);
-    int      table_mode = far_mode;
+    lp.block      = best_block(far_mode, &waves_global);
+    lp.table_mode = far_mode;
     if (lds_fits) {
         const uint32_t block_lds = best_block(kTableLds, &waves_lds);
         // the VALU filter reads one sphere per instruction from the table: for it LDS residency matters more than waves
-        if (filter == kFilterValu || waves_lds >= waves_global) { table_mode = kTableLds; block = block_lds; }
+        if (filter == kFilterValu || waves_lds >= waves_global) { lp.table_mode = kTableLds; lp.block = block_lds; }
     }
-    size_t lds_bytes = trace_lds_bytes(filter, table_mode, c->n, c->n_pad, c->n_pad_mfma, block);
-    if (const char* pad = getenv("RTX_LDS_PAD")) lds_bytes += (size_t)atoi(pad);      // tuning aid: lowers the occupancy
-    const int    occ       = trace_occupancy(filter, table_mode, lds_bytes, block);
-    const uint32_t max_grid = (uint32_t)c->num_cu * (uint32_t)occ;
-    const uint64_t lanes    = (uint64_t)max_grid * block;
+    lp.lds_bytes = trace_lds_bytes(filter, lp.table_mode, c->n, c->n_pad, c->n_pad_mfma, lp.block) + (size_t)t.lds_pad;
+    lp.max_grid  = (uint32_t)c->num_cu * (uint32_t)trace_occupancy(filter, lp.table_mode, lp.lds_bytes, lp.block);
+    lp.valid     = true;
+    return lp;
+}
 
-    // sample chunking: one chunk reproduces the reference's summation order exactly; the automatic choice trades that for
-    // a short tail.  When the work counter runs dry every lane still finishes its current (and its wave's prefetched)
-    // item while more and more lanes idle, so the kernel loses about five mean item durations (they are heavy-tailed): 12 ms of 75 with 56-sample
-    // items on the bench frame, 1 ms with 8-sample ones (profiles/r01e_item_granularity.txt).  256 items per lane keep that
-    // loss under 1 %; at most 64 chunks keep the partial sums (16 B x pixels x chunks) at 1 GB for 1200 x 800.
-    if (chunk_spp == 0) {
-        const uint64_t per_lane  = getenv("RTX_ITEMS_PER_LANE") ? (uint64_t)atoi(getenv("RTX_ITEMS_PER_LANE")) : 256u;
-        const uint64_t max_chunk = getenv("RTX_MAX_CHUNKS") ? (uint64_t)atoi(getenv("RTX_MAX_CHUNKS")) : 64u;
-        uint64_t nch = (lanes * per_lane + npix - 1) / npix;
-        nch = std::max<uint64_t>(1, std::min<uint64_t>(nch, std::min<uint64_t>(spp_count, std::max<uint64_t>(max_chunk, 1))));
-        nch = std::max<uint64_t>(1, std::min<uint64_t>(nch, ((1ull << 31) - 1) / npix));      // item indices are 31 bits
-        chunk_spp = (uint32_t)((spp_count + nch - 1) / nch);
+// Device buffers a launch works in: the context's own (allocated on demand) or the static scratch (rtx_render_noalloc).
+struct RenderBuffers {
+    float*    accum = nullptr;
+    float4*   partials = nullptr; size_t partials_items = 0;
+    uint32_t* work_counter = nullptr;
+    unsigned long long* stats = nullptr;
+    uint32_t* primary = nullptr;
+    float4*   att_stack = nullptr; size_t att_stack_items = 0;
+};
+
+// Everything of a render that is arithmetic on the host: argument checks, filter choice, launch geometry, chunk plan.
+struct RenderSetup {
+    TraceParams P{};
+    int         filter = kFilterMfma;
+    LaunchPlan  lp;
+    uint32_t    npix = 0, nchunks = 0, n_items = 0, grid = 0;
+    bool        accumulate = false, validate = false, fill_only = false;
+    uint64_t    att_entries = 0;
+};
+
+static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                        uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint64_t max_items, RenderSetup* out)
+{
+    if (!c) return fail(RTX_ERR_ARG, "%s: ctx is NULL", who);
+    if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "%s: upload a scene and a camera first", who);
+    if (cols == 0 || rows == 0 || spp_count == 0) return fail(RTX_ERR_ARG, "%s: cols, rows and spp_count must be non-zero", who);
+    if ((uint64_t)cols * rows > (1ull << 28)) return fail(RTX_ERR_ARG, "%s: image of %u x %u exceeds 2^28 pixels", who, cols, rows);
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_ARG, "%s: sample range overflows 32 bits", who);
+    if (flags & ~(uint32_t)(RTX_FLAG_ACCUMULATE | RTX_FLAG_RECURSIVE | RTX_FLAG_VALIDATE_FILTER)) return fail(RTX_ERR_ARG, "%s: unknown flag bits 0x%x", who, flags);
+    RenderSetup& R = *out;
+    R.npix       = cols * rows;
+    R.accumulate = (flags & RTX_FLAG_ACCUMULATE) != 0;
+    R.validate   = (flags & RTX_FLAG_VALIDATE_FILTER) != 0;
+    R.fill_only  = max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE);
+    if (R.fill_only) return RTX_OK;
+
+    R.filter = c->filter;
+    if (R.filter == kFilterMfma) {
+        // primary rays start on the lens (camera.h:75-86); bounce rays start on spheres, which the scale already covers
+        bool fits = c->mfma_ok;
+        double reach2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double reach = std::fabs((double)c->cam.origin[k]) + std::fabs((double)c->cam.lens_radius) * (std::fabs((double)c->cam.u[k]) + std::fabs((double)c->cam.v[k]));
+            reach2 += reach * reach;
+        }
+        fits = fits && std::isfinite(reach2) && std::sqrt(reach2) <= c->mfma_omax;       // |o| of any point of the lens
+        if (!fits) R.filter = kFilterValu;
     }
-    if (chunk_spp > spp_count) chunk_spp = spp_count;
-    const uint32_t nchunks = (spp_count + chunk_spp - 1) / chunk_spp;
-    const uint64_t n_items64 = (uint64_t)npix * nchunks;
-    if (n_items64 >= (1ull << 31)) return fail(RTX_ERR_ARG, "rtx_render: %llu work items; raise chunk_spp", (unsigned long long)n_items64);
-    const uint32_t n_items = (uint32_t)n_items64;
+    R.lp = launch_plan(c, R.filter);
+    const uint64_t lanes = (uint64_t)R.lp.max_grid * R.lp.block;
+    const uint64_t npix  = R.npix;
+
+    TraceParams& P = R.P;
+    uint32_t first_len;                      // size of the largest chunk: a wave's reservation is served lane by lane, one item after another
+    if (chunk_spp == 0) {
+        max_items = std::min<uint64_t>(max_items, (1ull << 31) - 1);
+        if (npix > max_items) return fail(RTX_ERR_ARG, "%s: %llu pixels need more than the %llu work items the partial-sum scratch holds", who, (unsigned long long)npix, (unsigned long long)max_items);
+        R.nchunks = plan_chunks(spp_count, npix, lanes, (uint32_t)c->tune.items_per_lane, (uint32_t)c->tune.max_chunks, (uint32_t)c->tune.tail_factor, max_items, P.chunk_tab);
+        first_len = P.chunk_tab[1];
+    } else {
+        if (chunk_spp > spp_count) chunk_spp = spp_count;
+        R.nchunks = (spp_count + chunk_spp - 1) / chunk_spp;
+        first_len = chunk_spp;
+    }
+    const uint64_t n_items64 = npix * R.nchunks;
+    if (n_items64 >= (1ull << 31)) return fail(RTX_ERR_ARG, "%s: %llu work items; raise chunk_spp", who, (unsigned long long)n_items64);
+    if (n_items64 > max_items) return fail(RTX_ERR_ARG, "%s: %llu work items exceed the %llu that the partial-sum scratch holds; raise chunk_spp", who, (unsigned long long)n_items64, (unsigned long long)max_items);
+    R.n_items = (uint32_t)n_items64;
     // Reservation size: every trip to the one global counter is a device-scope atomic on one address, and 4096 waves taking
     // 64 one-sample items at a time saturate it (200 spp as 1-sample items: 34.7 ms with 64-item reservations, 24.6 ms with
-    // 256); a wave therefore reserves about 512 samples' worth at 512 spheres, at least 64 items (the tail grows with it, see above).
+    // 256); a wave therefore reserves about 512 samples' worth at 512 spheres, at least 64 items (the tail grows with it).
     // Larger tables mean longer bounce iterations and fewer trips, so the target shrinks with the table.
     uint32_t wave_batch = kWaveBatch;
     const uint64_t target = 512ull * 512ull / std::max<uint32_t>(c->n_pad, 512u);
-    while (wave_batch < 512u && (uint64_t)wave_batch * 2u * chunk_spp <= target) wave_batch *= 2u;
-    if (const char* e = getenv("RTX_WAVE_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096) wave_batch = (uint32_t)v; }
-    if ((uint64_t)n_items + (uint64_t)max_grid * (block / 64u) * 2u * wave_batch >= (1ull << 32)) return fail(RTX_ERR_ARG, "rtx_render: work counter would overflow; raise chunk_spp");
-    rc = ensure(&c->partials, &c->partials_items, (size_t)n_items);
-    if (rc) return rc;
-    if (want_primary) {
-        rc = ensure(&c->primary, &c->primary_items, (size_t)npix * spp_count);
-        if (rc) return rc;
-    }
+    while (wave_batch < 512u && (uint64_t)wave_batch * 2u * first_len <= target) wave_batch *= 2u;
+    if (c->tune.wave_batch) wave_batch = (uint32_t)c->tune.wave_batch;
+    if ((uint64_t)R.n_items + (uint64_t)R.lp.max_grid * (R.lp.block / 64u) * 2u * wave_batch >= (1ull << 32)) return fail(RTX_ERR_ARG, "%s: work counter would overflow; raise chunk_spp", who);
 
-    TraceParams P{};
     P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.mfma_scale = c->mfma_scale; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
-    P.cols = cols; P.rows = rows; P.npix = npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = nchunks;
-    P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = n_items; P.wave_batch = wave_batch;
-    P.partials = c->partials; P.primary = want_primary ? c->primary : nullptr; P.work_counter = c->work_counter;
-    P.stats = want_stats ? c->stats : nullptr;
+    P.cols = cols; P.rows = rows; P.npix = R.npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = R.nchunks;
+    P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = R.n_items; P.wave_batch = wave_batch;
+    if (flags & RTX_FLAG_RECURSIVE) R.att_entries = (uint64_t)std::max<uint32_t>(max_depth, 1u) * R.lp.max_grid * R.lp.block;
+    const uint32_t blocks_needed = (uint32_t)((n_items64 + R.lp.block - 1) / R.lp.block);
+    R.grid = std::max<uint32_t>(1, std::min<uint32_t>(R.lp.max_grid, blocks_needed));
+    memcpy(c->last_tab, P.chunk_tab, sizeof(c->last_tab));
+    c->last_nchunks = R.nchunks; c->last_chunk_spp = chunk_spp;
+    return RTX_OK;
+}
 
-    HIP_TRY(hipMemsetAsync(c->work_counter, 0, 256, c->stream));
-    if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
-    if (flags & RTX_FLAG_RECURSIVE) {
-        // -r multiplies the attenuations innermost first (raytracer.cpp:232), so every lane keeps them until its path ends
-        const uint64_t entries = (uint64_t)std::max<uint32_t>(max_depth, 1u) * max_grid * block;
-        if (entries * sizeof(float4) > (8ull << 30)) return fail(RTX_ERR_ARG, "rtx_render: RTX_FLAG_RECURSIVE with max_depth %u needs a %llu MiB attenuation stack; the limit is 8 GiB", max_depth, (unsigned long long)(entries * sizeof(float4) >> 20));
-        rc = ensure(&c->att_stack, &c->att_stack_items, (size_t)entries);
-        if (rc) return rc;
-        P.att_stack = c->att_stack;
+// Puts the launches of one render on the context's stream.  Allocates nothing.
+static int launch_render(rtx_ctx* c, RenderSetup& R, const RenderBuffers& B, uint32_t spp_count)
+{
+    if (!c->ev_open) { HIP_TRY(hipEventRecord(c->ev_first, c->stream)); c->ev_open = true; }
+    if (B.stats) HIP_TRY(hipMemsetAsync(B.stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
+    if (R.fill_only) {
+        // raytracer.cpp:250: the bounce loop does not run, _color returns (1,1,1) for every sample (-r still traces the primary ray)
+        launch_fill(B.accum, R.npix * 3, (float)spp_count, R.accumulate, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_last, c->stream));
+        return RTX_OK;
     }
-    const uint32_t blocks_needed = (uint32_t)((n_items64 + block - 1) / block);
-    const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(max_grid, blocks_needed));
+    TraceParams& P = R.P;
+    P.partials = B.partials; P.primary = B.primary; P.work_counter = B.work_counter; P.stats = B.stats; P.att_stack = B.att_stack;
+    HIP_TRY(hipMemsetAsync(B.work_counter, 0, 256, c->stream));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
-    HIP_TRY(launch_trace(P, filter, table_mode, validate, grid, block, lds_bytes, c->stream));
+    HIP_TRY(launch_trace(P, R.filter, R.lp.table_mode, R.validate, R.grid, R.lp.block, R.lp.lds_bytes, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     c->ev_trace = true;
-    launch_reduce(c->partials, c->accum, npix, nchunks, accumulate, c->stream);
+    launch_reduce(B.partials, B.accum, R.npix, R.nchunks, R.accumulate, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_last, c->stream));
+    return RTX_OK;
+}
+
+static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                          uint64_t seed, uint32_t flags, uint32_t chunk_spp, bool want_primary, bool want_stats)
+{
+    RenderSetup R;
+    if (c) HIP_TRY(hipSetDevice(c->device));
+    const uint64_t cap_items = c ? ((uint64_t)c->tune.partials_mb << 20) / sizeof(float4) : 0;
+    int rc = setup_render(c, "rtx_render", cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, cap_items, &R);
+    if (rc) return rc;
+    if (R.accumulate && (c->cols != cols || c->rows != rows || !c->accum)) return fail(RTX_ERR_STATE, "rtx_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
+    if (c->cols != cols || c->rows != rows) { HIP_TRY(hipStreamSynchronize(c->stream)); }
+    if (c->accum_borrowed) {
+        if (c->accum_floats != (size_t)R.npix * 3) return fail(RTX_ERR_STATE, "rtx_render: the caller's accumulation buffer holds %zu floats, this image needs %zu", c->accum_floats, (size_t)R.npix * 3);
+    } else {
+        rc = ensure(&c->accum, &c->accum_floats, (size_t)R.npix * 3);
+        if (rc) return rc;
+    }
+    c->cols = cols; c->rows = rows;
+    RenderBuffers B;
+    B.accum = c->accum; B.work_counter = c->work_counter; B.stats = want_stats ? c->stats : nullptr;
+    if (!R.fill_only) {
+        rc = ensure(&c->partials, &c->partials_items, (size_t)R.n_items);
+        if (rc) return rc;
+        B.partials = c->partials; B.partials_items = c->partials_items;
+        if (want_primary) {
+            rc = ensure(&c->primary, &c->primary_items, (size_t)R.npix * spp_count);
+            if (rc) return rc;
+            B.primary = c->primary;
+        }
+        if (R.att_entries) {
+            // -r multiplies the attenuations innermost first (raytracer.cpp:232), so every lane keeps them until its path ends
+            if (R.att_entries * sizeof(float4) > (8ull << 30)) return fail(RTX_ERR_ARG, "rtx_render: RTX_FLAG_RECURSIVE with max_depth %u needs a %llu MiB attenuation stack; the limit is 8 GiB", max_depth, (unsigned long long)(R.att_entries * sizeof(float4) >> 20));
+            rc = ensure(&c->att_stack, &c->att_stack_items, (size_t)R.att_entries);
+            if (rc) return rc;
+            B.att_stack = c->att_stack;
+        }
+    }
+    return launch_render(c, R, B, spp_count);
+}
+
+extern "C" int rtx_last_chunk_plan(rtx_ctx* c, uint32_t* chunk_spp, uint32_t* n_chunks, uint32_t* starts, uint32_t cap)
+{
+    if (!c || !chunk_spp || !n_chunks) return fail(RTX_ERR_ARG, "rtx_last_chunk_plan: NULL argument");
+    *chunk_spp = c->last_chunk_spp;
+    *n_chunks  = c->last_nchunks;
+    if (c->last_chunk_spp == 0u && c->last_nchunks != 0u) {
+        if (!starts || cap < c->last_nchunks + 1u) return fail(RTX_ERR_ARG, "rtx_last_chunk_plan: %u boundaries do not fit into %u entries", c->last_nchunks + 1u, cap);
+        memcpy(starts, c->last_tab, (c->last_nchunks + 1u) * sizeof(uint32_t));
+    }
     return RTX_OK;
 }
 
@@ -477,7 +595,7 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     if (stats) {
         unsigned long long h[kStCount + 12];
         HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
-        if (getenv("RTX_PRINT_PHASES")) {
+        if (c->tune.print_phases) {
             static const char* names[12] = { "A fetch", "B camera", "C filter tiles", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish", "C filter setup", "C push words", "C peel + enqueue", "C exact batches" };
             unsigned long long tot = 0;
             for (int k = 0; k < 12; ++k) tot += h[kStCount + k];

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "../../include/rtx.h"
+#include "rtx_plan.h"
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,6 +18,7 @@ constexpr uint32_t kMaxBlock   = 512;                  // threads per workgroup 
 constexpr uint32_t kWaveBatch  = 64;                    // smallest reservation of work items (TraceParams::wave_batch)
 constexpr uint32_t kWaveLdsBytes = 4608;               // per wave: 64 ray records (2 KB), 64 result slots (512 B), 256 candidate entries (1 KB), 128 sign-word entries (1 KB)
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
+constexpr uint32_t kChunkTabBytes = 256;               // the LDS copy of the boundaries, in front of everything else
 // MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) + kMfmaAbsMargin / scale^2 per sphere and gamma * |o|^2 per
 // ray, gamma = 2^-16 = 256 ulp (ulp = 2^-24).  Budget, in ulp of (|C|^2 + |o|^2), for the single quadratic form: a monomial
 // is x1 p1 + x1 p2 + x2 p1 with both factors split to 2^-22, i.e. 12 ulp of |monomial x coefficient|; the coefficients
@@ -52,7 +54,8 @@ struct TraceParams {
     uint32_t      n, n_pad;
     rtx_camera    cam;
     uint32_t      cols, rows, npix;
-    uint32_t      spp_begin, spp_count, chunk_spp, nchunks;
+    uint32_t      spp_begin, spp_count, chunk_spp, nchunks;   // chunk_spp != 0: uniform chunks; 0: chunk k covers samples [chunk_tab[k], chunk_tab[k+1]) of the range
+    uint32_t      chunk_tab[kMaxPlanChunks + 1];
     uint32_t      max_depth, key0, key1, flags;
     uint32_t      n_items;
     uint32_t      wave_batch; // work items a wave reserves per trip to the global counter (host: about 512 samples' worth)

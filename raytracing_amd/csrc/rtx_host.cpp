@@ -2,6 +2,9 @@
 // and the PPM writer.  None of them touches a GPU.  Compiled with contraction off: the camera must come out
 // bit-identical to what the reference's Camera constructor (camera.h:20-41) computes with the same arguments.
 #include "../../include/rtx.h"
+#include "rtx_plan.h"
+
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -42,6 +45,55 @@ struct SceneDraws {
     }
 };
 } // namespace
+
+// Sample chunking.  A work item is (chunk, pixel): a lane adds the chunk's samples of its pixel in registers, in sample
+// order, and stores one partial sum; reduce_kernel adds a pixel's partial sums in chunk order -- deterministic, no atomics.
+// One chunk reproduces the reference's summation order exactly (raytracer.cpp:184); more chunks trade that for a short
+// tail: when the work counter runs dry every lane still finishes its current item while more and more lanes idle.
+// Round 1 used uniform chunks (8 samples on the bench frame: 64 chunks, 983 MB of partial sums).  What the tail needs is
+// small items at the END only, so the plan is geometric: chunk sizes shrink by r per chunk down to s_min, which is sized
+// for `items_per_lane` items per lane.  r follows from the requirement that an item of chunk k that takes h mean item
+// durations (pixels on glass run up to 50 bounces per sample) still ends before the launch does: the work behind chunk k
+// must cover h item durations of every lane, i.e. sum_{j>k} B_j >= h rho B_k with rho = lanes / pixels, so
+// r / (1 - r) = h rho.  tab[0..nch] receives the boundaries relative to spp_begin; at most max_items work items.
+uint32_t rtx::plan_chunks(uint32_t spp_count, uint64_t npix, uint64_t lanes, uint32_t items_per_lane, uint32_t max_chunks, uint32_t tail_factor, uint64_t max_items, uint32_t* tab)
+{
+    uint64_t allowed = std::min<uint64_t>((uint64_t)std::max<uint32_t>(max_chunks, 1u), rtx::kMaxPlanChunks);
+    allowed = std::max<uint64_t>(1, std::min<uint64_t>(allowed, std::min<uint64_t>(spp_count, max_items / npix)));
+    const double rho = (double)lanes / (double)npix;
+    const double hr  = (double)tail_factor * rho;
+    const double r   = std::min(0.96, std::max(0.2, hr / (1.0 + hr)));
+    uint64_t s_min = std::max<uint64_t>(1, ((uint64_t)spp_count * npix + lanes * (uint64_t)items_per_lane - 1) / (lanes * (uint64_t)items_per_lane));
+    for (;;) {
+        uint32_t nch = 0, done = 0;
+        double   b = std::max<double>((double)s_min, std::floor((double)spp_count * (1.0 - r) + 0.5));
+        tab[0] = 0;
+        while (done < spp_count && nch < allowed) {
+            uint32_t len = (uint32_t)std::max<double>((double)s_min, std::floor(b));
+            if (len > spp_count - done || nch + 1 == allowed) len = spp_count - done;
+            done += len;
+            tab[++nch] = done;
+            b *= r;
+        }
+        // the last allowed chunk swallowed the rest: acceptable only if it is not larger than its predecessor
+        const bool ok = nch < 2 || (tab[nch] - tab[nch - 1]) <= (tab[nch - 1] - tab[nch - 2]) || allowed <= 2;
+        if (ok) return nch;
+        s_min = s_min + (s_min + 1) / 2;          // fewer, larger small chunks
+        if (s_min >= spp_count) {                 // degenerate: an even split
+            for (uint32_t k = 0; k <= allowed; ++k) tab[k] = (uint32_t)((uint64_t)spp_count * k / allowed);
+            return (uint32_t)allowed;
+        }
+    }
+}
+
+extern "C" int rtx_plan_chunks(uint32_t spp_count, uint64_t n_pixels, uint64_t lanes, uint32_t items_per_lane, uint32_t max_chunks,
+                               uint32_t tail_factor, uint64_t max_items, uint32_t* starts, uint32_t cap, uint32_t* n_chunks)
+{
+    if (!starts || !n_chunks || cap < rtx::kMaxPlanChunks + 1u || spp_count == 0 || n_pixels == 0 || lanes == 0 || items_per_lane == 0 || tail_factor == 0) return RTX_ERR_ARG;
+    if (n_pixels > max_items) return RTX_ERR_ARG;
+    *n_chunks = rtx::plan_chunks(spp_count, n_pixels, lanes, items_per_lane, max_chunks, tail_factor, max_items, starts);
+    return RTX_OK;
+}
 
 extern "C" int rtx_camera_init(rtx_camera* cam, float vfov, float aspect, float aperture, float focus, const float pos[3], const float up[3], const float lookat[3])
 {

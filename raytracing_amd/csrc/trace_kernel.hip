@@ -137,21 +137,26 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     //     64 B per sphere -- the f16 A operands of 32-sphere tiles, two MFMAs each, plus one spare tile -- for the MFMA filter)
     const float4* table = (FILTER == kFilterMfma) ? P.hot_mfma : P.hot;
     const uint32_t table_f4 = (FILTER == kFilterMfma) ? (P.n_pad_mfma + 32u) * 4u : P.n_pad;
+    // sample-chunk boundaries of this launch (TraceParams::chunk_tab), kChunkTabBytes at the very front of the LDS
+    uint32_t* const ctab = reinterpret_cast<uint32_t*>(smem);
+    if (P.chunk_spp == 0u)
+        for (uint32_t i = threadIdx.x; i <= P.nchunks; i += blockDim.x) ctab[i] = P.chunk_tab[i];
+    float4* const lds0 = smem + kChunkTabBytes / 16u;
     float4* wave_lds;
     const float4* exact = P.exact;
     if (LDS_TABLE) {
         // table, then the exact (cx, cy, cz, r) records the candidate re-test reads, then the per-wave areas
-        for (uint32_t i = threadIdx.x; i < table_f4; i += blockDim.x) smem[i] = table[i];
-        for (uint32_t i = threadIdx.x; i < P.n; i += blockDim.x) smem[table_f4 + i] = P.exact[i];
-        __syncthreads();
-        table = smem;
-        exact = smem + table_f4;
-        wave_lds = smem + table_f4 + ((P.n + 3u) & ~3u);
+        for (uint32_t i = threadIdx.x; i < table_f4; i += blockDim.x) lds0[i] = table[i];
+        for (uint32_t i = threadIdx.x; i < P.n; i += blockDim.x) lds0[table_f4 + i] = P.exact[i];
+        table = lds0;
+        exact = lds0 + table_f4;
+        wave_lds = lds0 + table_f4 + ((P.n + 3u) & ~3u);
     } else if (STREAM) {
-        wave_lds = smem + kStreamStageBytes / 16u;      // the stage comes first
+        wave_lds = lds0 + kStreamStageBytes / 16u;      // the stage comes first
     } else {
-        wave_lds = smem;
+        wave_lds = lds0;
     }
+    __syncthreads();
     // per wave (kWaveLdsBytes): 64 ray records (o, a | d, -) that the candidate re-test gathers from -- the MFMA filter
     // first uses the same 2 KB to hand its per-ray operands around --, 64 result slots, and the candidate queue
     wave_lds += wave * (kWaveLdsBytes / 16u);
@@ -209,9 +214,14 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     uint32_t chunk = it / P.npix;
                     pix            = it - chunk * P.npix;
                     prow           = pix / P.cols;                     // once per item, not per sample
-                    s_cur          = P.spp_begin + chunk * P.chunk_spp;
-                    uint32_t e     = s_cur + P.chunk_spp, lim = P.spp_begin + P.spp_count;
-                    s_end          = e < lim ? e : lim;
+                    if (P.chunk_spp) {                                    // uniform chunks (caller's choice)
+                        s_cur          = P.spp_begin + chunk * P.chunk_spp;
+                        uint32_t e     = s_cur + P.chunk_spp, lim = P.spp_begin + P.spp_count;
+                        s_end          = e < lim ? e : lim;
+                    } else {                                              // the launch's chunk plan: large chunks first, small ones last
+                        s_cur = P.spp_begin + ctab[chunk];
+                        s_end = P.spp_begin + ctab[chunk + 1u];
+                    }
                     acc            = mk(0, 0, 0);
                     st             = kNeedSample;
                 } else {
@@ -295,18 +305,18 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     uint32_t       i   = ent & 0x03FFFFFFu;
                     if (FILTER == kFilterMfma) i ^= 31u;     // (group, word, bit) -> sphere index, see the extraction below
                     const float4 r0 = rayrec[ray * 2u], r1 = rayrec[ray * 2u + 1u];
-                    const float4 s  = exact[i];
+                    const float4 s  = exact[i < P.n ? i : 0u];
                     const V3    ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
                     const float ra = r0.w;
                     const V3    oc = sub(ro, mk(s.x, s.y, s.z));
                     const float bq = dot(oc, rd);
                     const float cq = dot(oc, oc) - (s.w * s.w);
                     const float disc = bq * bq - ra * cq;
-                    if (disc > 0) {
+                    if (disc > 0 && i < P.n) {            // i >= n: a padded row, flagged only by a NaN / Inf ray (the reference finds no hit for one)
                         const float sq = sqrtf(disc);
                         float       t  = (-bq - sq) / ra;
                         if (!(t > 0.001f)) t = (-bq + sq) / ra;
-                        if (t > 0.001f)
+                        if (t > 0.001f && t < 3.402823466e+38f)    // sphere.cpp:81,90: t < max, and max starts at FLT_MAX
                             __hip_atomic_fetch_min(&res[ray], ((unsigned long long)__float_as_uint(t) << 32) | i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
@@ -428,7 +438,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 // "chunk g has landed" and the "chunk g - 1 is no longer read" directions.
                 const uint32_t nwaves     = blockDim.x >> 6;
                 const uint32_t wave_u     = uniform(wave);
-                const uint32_t stage_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)smem;
+                const uint32_t stage_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)lds0;
                 auto stage_chunk = [&](uint32_t g) {
                     for (uint32_t u = wave_u; u < 8u; u += nwaves)
                         glds16(reinterpret_cast<const uint4*>(P.hot_mfma) + ((size_t)g * 8u + u) * 64u + lane, stage_addr + ((g & 1u) << 13) + (u << 10));
@@ -437,7 +447,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 h8v A0_next, A1_next;
                 if (!STREAM) { A0_next = __builtin_bit_cast(h8v, tabA[0]); A1_next = __builtin_bit_cast(h8v, tabA[64]); }
                 for (uint32_t base = 0; base < P.n_pad_mfma; base += 128u) {
-                    const uint4* stage = reinterpret_cast<const uint4*>(smem) + (((base >> 7) & 1u) << 9) + lane;
+                    const uint4* stage = reinterpret_cast<const uint4*>(lds0) + (((base >> 7) & 1u) << 9) + lane;
                     if (STREAM) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __syncthreads();
@@ -784,7 +794,7 @@ size_t trace_lds_bytes(int filter, int table_mode, uint32_t n, uint32_t n_pad, u
     const bool   lds_table = table_mode == kTableLds;
     const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 64 : (size_t)n_pad * 16) : (table_mode == kTableStream ? kStreamStageBytes : 0);
     const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
-    return table + exact + (size_t)(block / 64) * kWaveLdsBytes;
+    return kChunkTabBytes + table + exact + (size_t)(block / 64) * kWaveLdsBytes;
 }
 
 int trace_occupancy(int filter, int table_mode, size_t lds_bytes, uint32_t block)

@@ -55,6 +55,7 @@ int main(int argc, char** argv)
     if (args.cmdOptionExists("-c") || args.cmdOptionExists("-i")) { printf("Error: this build contains the HIP backend only (-g); -c and -i are not available.\n"); return -1; }
     int aaSamples = 24;                                            // NUM_AA_SAMPLES, RayTracing.cpp:31
     if (args.cmdOptionExists("-a")) aaSamples = std::stoi(args.getCmdOption("-a"));
+    if (aaSamples <= 0) { printf("Error: -a needs a positive sample count.\n"); return -1; }
     int blockSize = 64;
     if (args.cmdOptionExists("-b")) blockSize = std::stoi(args.getCmdOption("-b"));
     bool debug = args.cmdOptionExists("-d");
@@ -90,7 +91,7 @@ int main(int argc, char** argv)
     if (!probe) { printf("Error: failed to open [%s] for writing.\n", filename.c_str()); delete scene; return -1; }
     fclose(probe);
 
-    rtx_stats st;
+    rtx_stats st{};
     struct PassCtx { std::string file; unsigned cols, rows, total; bool binary; } pc{ filename, cols, rows, (unsigned)aaSamples, binary };
     HipRenderOptions opt;
     opt.seed = seed; opt.device = device; opt.stats = &st; opt.pass_spp = passSpp; opt.resume = resume;
@@ -107,8 +108,9 @@ int main(int argc, char** argv)
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != 0) { delete scene; return -1; }
     printf("renderSceneHIP: %f s (%zu spheres, %u x %u, %d spp, depth %d)\n", sec, scene->objects.size(), cols, rows, aaSamples, maxBounce);
-    printf("{\"msamples_per_s\": %.3f, \"mrays_per_s\": %.3f, \"kernel_ms\": %.3f, \"rays\": %llu, \"samples\": %llu}\n",
-           st.samples / (st.kernel_ms * 1e3), st.rays / (st.kernel_ms * 1e3), st.kernel_ms, (unsigned long long)st.rays, (unsigned long long)st.samples);
+    if (st.kernel_ms > 0.0)      // no pass ran (-R on a finished checkpoint): there is nothing to report
+        printf("{\"msamples_per_s\": %.3f, \"mrays_per_s\": %.3f, \"kernel_ms\": %.3f, \"rays\": %llu, \"samples\": %llu}\n",
+               st.samples / (st.kernel_ms * 1e3), st.rays / (st.kernel_ms * 1e3), st.kernel_ms, (unsigned long long)st.rays, (unsigned long long)st.samples);
     rc = binary ? rtx_write_ppm_p6(filename.c_str(), cols, rows, frameBuffer.data()) : rtx_write_ppm(filename.c_str(), cols, rows, frameBuffer.data());
     delete scene;
     return rc == 0 ? 0 : -1;

@@ -78,6 +78,9 @@ class TorchAccum:
         self.torch = torch
         self.ctx = ctx
         self.t = torch.zeros(rows * cols * 3, dtype=torch.float32, device=device)
+        # librtx works on its own non-blocking stream, which never waits for torch's: anything torch has queued on a
+        # buffer (here the zero fill) must be complete before its address is handed over
+        torch.cuda.current_stream(device).synchronize()
         ctx.use_accum_buffer(cols, rows, self.t.data_ptr())
 
     def allreduce(self):
@@ -89,7 +92,9 @@ class TorchAccum:
     def snapshot(self):
         """A copy of this rank's running buffer (for an exchange that must not disturb it)."""
         self.ctx.sync()
-        return self.t.clone()
+        c = self.t.clone()
+        self.torch.cuda.current_stream(self.t.device).synchronize()      # the copy runs on torch's stream; resolve_tensor reads it on librtx's
+        return c
 
     def allreduce_tensor(self, t):
         import torch.distributed as dist

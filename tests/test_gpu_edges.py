@@ -261,10 +261,10 @@ def test_config5_full_size_properties(ra, ctx, golden_scenes, monkeypatch):
     assert st["samples"] == cols * rows * spp and st["sphere_tests"] == st["rays"] * len(table)
     assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
     assert st["candidates"] < 3.0 * st["rays"]
-    monkeypatch.setenv("RTX_STREAM", "0")
+    ctx.set_tuning("stream", 0)
     _, st2 = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=4)
     assert (bits(ctx.read_accum()) == bits(streamed)).all() and st2["rays"] == st["rays"]
-    monkeypatch.delenv("RTX_STREAM")
+    ctx.set_tuning("stream", -1)
     ctx.set_filter(ra.FILTER_VALU)
     _, st3 = ctx.render(cols, rows, 0, 4, 50, 1, chunk_spp=4)            # the VALU filter is 6x slower here: one chunk of it
     valu = ctx.read_accum()
@@ -304,3 +304,27 @@ def test_one_hip_runtime_whichever_import_comes_first(torch_first):
     code += "; m = open('/proc/self/maps').read(); n = len({l.split()[-1] for l in m.splitlines() if 'libamdhip64' in l}); assert n == 1, n"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("cols,rows,spp,begin,knobs", [(96, 64, 37, 0, {}), (75, 50, 16, 3, {"max_chunks": 3}), (300, 200, 9, 0, {"items_per_lane": 4, "tail_factor": 1})])
+def test_automatic_chunk_plan_is_bit_exact_against_the_oracle(ra, ctx, oracle, golden_scenes, cols, rows, spp, begin, knobs):
+    """chunk_spp = 0 (what bench.py and the CLI launch): the library reports the chunk boundaries it chose
+    (rtx_last_chunk_plan) and the oracle, summing in that same order, gives the same bits."""
+    table = golden_scenes["book1"]
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    for k, v in knobs.items():
+        ctx.set_tuning(k, v)
+    primary, st = ctx.render(cols, rows, begin, spp, 50, 11, want_primary=True)
+    accum = ctx.read_accum()
+    chunk_spp, starts = ctx.last_chunk_plan()
+    assert chunk_spp == 0 and starts[0] == 0 and starts[-1] == spp and (np.diff(starts.astype(np.int64)) > 0).all()
+    o_accum, o_primary, o_st = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, begin, spp, 50, 11, want_primary=True, chunk_starts=starts)
+    assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+    assert st["rays"] == o_st["rays"] and st["samples"] == o_st["samples"]
+    ctx.render(cols, rows, begin, spp, 50, 11, chunk_spp=5)
+    assert ctx.last_chunk_plan() == (5, None)
+    with pytest.raises(ra.RtxError):
+        ctx.set_tuning("no_such_knob", 1)
+    with pytest.raises(ra.RtxError):
+        ctx.set_tuning("block", 100)

@@ -123,10 +123,10 @@ def test_streamed_table_equals_the_oracle(ra, oracle, golden_scenes, monkeypatch
         table = golden_scenes["book1"][:0].copy()
     else:
         table = golden_scenes[scene]
-    monkeypatch.setenv("RTX_STREAM", "1")
-    if block:
-        monkeypatch.setenv("RTX_BLOCK", block)
     ctx = ra.Context(0)
+    ctx.set_tuning("stream", 1)
+    if block:
+        ctx.set_tuning("block", int(block))
     ctx.upload_scene(table)
     ctx.set_camera(ra.book_camera(cols, rows))
     primary, st = ctx.render(cols, rows, 0, spp, 50, 21, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
@@ -140,7 +140,7 @@ def test_streamed_table_equals_the_oracle(ra, oracle, golden_scenes, monkeypatch
     _, st2 = ctx.render(cols, rows, 0, spp, 50, 21, flags=ra.FLAG_RECURSIVE)
     o2, _, _ = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, 0, spp, 50, 21, recursive=True)
     np.testing.assert_allclose(ctx.read_accum(), o2, rtol=1e-5, atol=1e-6)      # chunked sums round differently
-    monkeypatch.setenv("RTX_STREAM", "0")
+    ctx.set_tuning("stream", 0)
     ctx.render(cols, rows, 0, spp, 50, 21, chunk_spp=spp)
     assert (bits(ctx.read_accum()) == bits(accum)).all()
     ctx.close()

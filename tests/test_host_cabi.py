@@ -166,3 +166,25 @@ int main(void)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "raytracing_amd" in r.stdout and "lens 0.050" in r.stdout and ("gpu" in r.stdout)
+
+
+def test_chunk_plan_properties():
+    """rtx_plan_chunks (pure host code): the automatic sample-chunk plan covers the range exactly, shrinks monotonically to
+    small items at the end, and stays inside its work-item budget -- 1200x800 at 500 spp under 300 MiB of partial sums
+    (round 1: 983 MB), 3840x2160 at 4096 spp under 1 GiB (round 1: 8.5 GB)."""
+    import raytracing_amd.api as api
+    lanes = 256 * 2048
+    for spp, npix, kw in [(500, 1200 * 800, {}), (4096, 3840 * 2160, {}), (100, 1200 * 800, {}), (10, 1200 * 800, {}), (1, 7, {}), (3, 1, {}),
+                          (500, 1200 * 800, {"max_items": 4 << 20}), (500, 1200 * 800, {"max_items": 1200 * 800}), (8192, 120 * 80, {}),
+                          (977, 300 * 200, {"max_chunks": 5}), (64, 1200 * 800, {"tail_factor": 2}), (50, 640 * 480, {"items_per_lane": 16})]:
+        t = api.plan_chunks(spp, npix, lanes, **kw)
+        d = np.diff(t.astype(np.int64))
+        assert t[0] == 0 and t[-1] == spp and (d > 0).all(), (spp, npix, kw, t)
+        assert (d[1:] <= d[:-1]).all(), (spp, npix, kw, d)                      # large chunks first
+        assert len(d) <= min(63, kw.get("max_chunks", 63)) and len(d) * npix <= kw.get("max_items", 1 << 26)
+    bench = api.plan_chunks(500, 1200 * 800, lanes)
+    assert (len(bench) - 1) * 1200 * 800 * 16 < 300 << 20 and bench[-1] - bench[-2] <= 8
+    big = api.plan_chunks(4096, 3840 * 2160, lanes)
+    assert (len(big) - 1) * 3840 * 2160 * 16 < 1 << 30
+    with pytest.raises(api.RtxError):
+        api.plan_chunks(10, 100, lanes, max_items=99)
