@@ -138,6 +138,19 @@ int rtx_render(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, u
  * available; 64 always suffice).  A CPU restatement summing in that same order reproduces an automatic launch bit for bit. */
 int rtx_last_chunk_plan(rtx_ctx* ctx, uint32_t* chunk_spp, uint32_t* n_chunks, uint32_t* starts, uint32_t cap);
 
+/* rtx_render for callers that cannot allocate: it calls no hipMalloc / hipFree and no routine that allocates.  It has no
+ * counterpart in the reference; it is for callers that must not allocate while they render -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid it.  Inputs are the scene and camera already uploaded to `ctx`; the
+ * output is accum_dev, cols*rows*3 floats of the CALLER's device memory on the context's GPU (colour sums as for
+ * rtx_render; RTX_FLAG_ACCUMULATE adds to what it holds).  The work counter and the partial sums live in a static device
+ * array of 64 MiB + 256 bytes that every GPU the library runs on holds until the process ends: a launch may use at most
+ * 4 194 304 work items (pixels x sample chunks; automatic plans shrink to fit, which lengthens the tail of large
+ * frames), more pixels than that fail with RTX_ERR_ARG.  RTX_FLAG_RECURSIVE (needs a per-lane stack) is refused; no
+ * primary-hit map, no statistics.  All calls on one GPU share that array: calls that overlap on a GPU -- from two
+ * contexts or two threads -- race.  Blocks until the image is complete. */
+int rtx_render_noalloc(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                       uint64_t seed, uint32_t flags, uint32_t chunk_spp, float* accum_dev);
+
 /* Same, but only enqueues the work on the context's stream and returns; rtx_sync() waits.  bench.py brackets
  * K of these with one rtx_sync.  Statistics and primary-hit maps are not available in this form. */
 int rtx_render_async(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,

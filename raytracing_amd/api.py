@@ -16,7 +16,7 @@ FILTER_VALU, FILTER_MFMA = 0, 1
 
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_set_camera", "rtx_render",
-           "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
+           "rtx_render_noalloc", "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
            "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks",
            "rtx_version"]
 
@@ -87,6 +87,7 @@ def lib():
     L.rtx_set_camera.argtypes = [C.c_void_p, P(CCamera)]
     L.rtx_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, up, P(Stats)]
     L.rtx_render_async.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32]
+    L.rtx_render_noalloc.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, C.c_void_p]
     L.rtx_sync.argtypes = [C.c_void_p]
     L.rtx_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double)]
     L.rtx_last_trace_ms.argtypes = [C.c_void_p, P(C.c_double)]
@@ -260,6 +261,11 @@ class Context:
                                 _up(primary) if want_primary else None, C.byref(st) if want_stats else None))
         self.cols, self.rows = cols, rows
         return primary, (st.as_dict() if want_stats else None)
+
+    def render_noalloc(self, cols, rows, spp_begin, spp_count, max_depth, seed, accum_dev_ptr, flags=0, chunk_spp=0):
+        """rtx_render_noalloc: renders into the caller's device buffer (integer address of cols*rows*3 floats) without
+        allocating; scratch is the library's static device array."""
+        _check(lib().rtx_render_noalloc(self._h, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, C.c_void_p(accum_dev_ptr)))
 
     def render_async(self, cols, rows, spp_begin, spp_count, max_depth, seed, flags=0, chunk_spp=0):
         _check(lib().rtx_render_async(self._h, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp))

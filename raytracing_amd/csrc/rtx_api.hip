@@ -12,6 +12,14 @@
 
 using namespace rtx;
 
+// Scratch of rtx_render_noalloc, the entry point that allocates nothing: work counter (first 256 bytes) + partial sums.
+// Every GPU the library runs on holds its own copy from module load until the process ends; in host code the array's name
+// is only a handle -- rtx_create asks the runtime for this device's address (hipGetSymbolAddress) and everything else
+// uses that pointer.
+constexpr size_t kScratchCounterBytes = 256;
+constexpr size_t kScratchPartialBytes = 64ull << 20;                         // 4 Mi work items of 16 bytes
+static __device__ __align__(256) unsigned char scratch[kScratchCounterBytes + kScratchPartialBytes];
+
 static thread_local std::string g_last_error;
 
 static int fail(int code, const char* fmt, ...)
@@ -123,6 +131,11 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
     if (e == hipSuccess) e = hipMalloc(&c->work_counter, 256);
     if (e == hipSuccess) e = hipMalloc(&c->stats, (kStCount + 12) * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));      // this device's copy (the device is current)
+        c->scratch = static_cast<unsigned char*>(p);
+    }
     if (e != hipSuccess) { rtx_destroy(c); return fail(RTX_ERR_DEVICE, "rtx_create: %s", hipGetErrorString(e)); }
     *out_ctx = c;
     return RTX_OK;
@@ -612,6 +625,30 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         }
         stats->kernel_ms = ms;
     }
+    return RTX_OK;
+}
+
+extern "C" int rtx_render_noalloc(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                                  uint64_t seed, uint32_t flags, uint32_t chunk_spp, float* accum_dev)
+{
+    if (!c || !accum_dev) return fail(RTX_ERR_ARG, "rtx_render_noalloc: NULL argument");
+    if (flags & RTX_FLAG_RECURSIVE) return fail(RTX_ERR_ARG, "rtx_render_noalloc: RTX_FLAG_RECURSIVE needs a per-lane attenuation stack, which this entry point has no memory for; use rtx_render");
+    if (!c->scratch) return fail(RTX_ERR_STATE, "rtx_render_noalloc: the context has no scratch address");
+    HIP_TRY(hipSetDevice(c->device));
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, accum_dev) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != c->device)
+        return fail(RTX_ERR_ARG, "rtx_render_noalloc: accum_dev is not device memory of GPU %d", c->device);
+    RenderSetup R;
+    int rc = setup_render(c, "rtx_render_noalloc", cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, kScratchPartialBytes / sizeof(float4), &R);
+    if (rc) return rc;
+    RenderBuffers B;
+    B.accum          = accum_dev;
+    B.work_counter   = reinterpret_cast<uint32_t*>(c->scratch);
+    B.partials       = reinterpret_cast<float4*>(c->scratch + kScratchCounterBytes);
+    B.partials_items = kScratchPartialBytes / sizeof(float4);
+    rc = launch_render(c, R, B, spp_count);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
 
