@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Adds statistical reference images to tests/golden/: the UNMODIFIED renderScene of the reference (thread pool, its own
 mt19937 draws; oracle/_ref/ref_harness render_ref) at 1024 spp on small frames, for the scenes / modes that
-oracle/gen_fixtures.py does not cover (glass-heavy iterative, book-1 with -r).  Runs here only (needs /root/reference
+oracle/gen_fixtures.py does not cover (glass-heavy iterative, book-1 with -r, the 1601-sphere scaled scene).  Runs here only (needs /root/reference
 compiled by `make -C oracle ref`); the outputs are data fixtures.  Existing entries are kept: the reference's stream is
 racy, so a re-run would not reproduce them bit for bit."""
 import json, os, subprocess, sys, tempfile
@@ -11,7 +11,7 @@ sys.path.insert(0, HERE)
 import pyoracle
 GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
-JOBS = {"glass_120x80_spp1024": ("glass", 0), "book1_120x80_spp1024_recursive": ("book1", 1)}
+JOBS = {"glass_120x80_spp1024": ("glass", 0), "book1_120x80_spp1024_recursive": ("book1", 1), "scaled_120x80_spp1024": ("scaled", 0)}
 
 def main():
     scenes = np.load(os.path.join(GOLDEN, "scenes.npz"))

@@ -1,8 +1,8 @@
-// Host replacement for the reference's utils.cu, which cannot compile on Linux (utils.cu:59 typo, device-only
-// symbols at :133,:147).  TEST INFRASTRUCTURE ONLY: linked into oracle/_ref/ref_harness, never into the product.
+// The random source behind the reference's own utils.cu (compiled by ref_utils_wrap.cpp).  TEST INFRASTRUCTURE ONLY:
+// linked into oracle/_ref/ref_harness, never into the product.
 //
-// pk::random / randomInUnitSphere / randomOnUnitDisk keep the semantics of utils.cu:65-94, but the uniform
-// floats come from one of three sources selected per thread by the harness:
+// pk::random / randomInUnitSphere / randomOnUnitDisk ARE utils.cu:65-94; only the uniform floats behind
+// `_random( _gen )` come from one of three sources selected per thread by the harness:
 //   - a ro_rng (the shared Philox stream of oracle/rt_oracle.h), for bit-exact path comparisons;
 //   - a schedule of ro_rng streams that advances by itself, for driving the reference's own _renderJob;
 //   - a std::mt19937 (the reference's generator, utils.cu:26-28), for unmodified renderScene runs.
@@ -57,58 +57,87 @@ static ro_rng* scheduled_rng_for_bare_call()
 }
 } // namespace refinject
 
+// ---- the source behind `_random( _gen )` of utils.cu:70 (hook in ref_utils_wrap.cpp) -------------------------------
+//
+// The shared stream is structured (rt_oracle.h): a sampler try is one Philox block, x, y, z in words 0, 1, 2.  The
+// reference writes `vector3( random(), random(), random() )` (utils.cu:79,90), whose evaluation order C++ leaves to the
+// compiler; g++ evaluates the LAST argument first.  draw() therefore hands out a try's words in the order in which this
+// compiler asks for them (probed once, below), so that the reference's point has the components the stream defines --
+// the loop, its exit condition and the 21-try limit are the reference's own object code.
+namespace refinject
+{
+enum SamplerMode { kBare = 0, kSphere = 1, kDisk = 2 };
+thread_local int      t_mode = kBare;
+thread_local uint32_t t_calls = 0, t_base = 0;
+
+static int  s_probe_next = 0;
+static int  probe_next() { return s_probe_next++; }
+struct ProbeTriple { int a, b, c; ProbeTriple(int x, int y, int z) : a(x), b(y), c(z) {} };
+static bool last_argument_first()
+{
+    static const bool v = [] { s_probe_next = 0; ProbeTriple p(probe_next(), probe_next(), probe_next()); return p.c == 0; }();
+    return v;
+}
+
+static ro_rng* current_rng() { return t_rng ? t_rng : (t_schedule ? &t_sched_rng : nullptr); }
+
+float draw()
+{
+    ro_rng* g = current_rng();
+    if (t_mode == kBare || !g) {
+        if (t_rng) return ro_random(t_rng);
+        if (t_schedule) return ro_random(scheduled_rng_for_bare_call());
+        static thread_local std::uniform_real_distribution<float> dist(0.0f, 1.0f);
+        return dist(thread_mt());
+    }
+    const uint32_t width = t_mode == kSphere ? 3u : 2u;
+    const uint32_t c = t_calls++, t = c / width, k = c % width;
+    const uint32_t comp = last_argument_first() ? (width - 1u - k) : k;
+    g->draws++;
+    if (g->inject) {                                     // function KATs: a flat list, a try's components in x, y, z order
+        const uint32_t i = t_base + t * width + comp;
+        return i < g->inject_n ? g->inject[i] : 0.5f;
+    }
+    float b[4];
+    if (t_mode == kSphere) {                             // event e, try t -> block t, words 0..2
+        ro_rng_block(g, g->event, t, b);
+        return b[comp];
+    }
+    if (t == 0) { ro_rng_block(g, 0, 0, b); return b[2 + comp]; }                    // disk try 0: words 2, 3 of block 0
+    ro_rng_block(g, 0, (t + 1) / 2, b);
+    return b[((t & 1) ? 0 : 2) + comp];
+}
+
+struct SamplerScope {
+    SamplerScope(int mode)
+    {
+        ro_rng* g = current_rng();
+        t_mode = mode; t_calls = 0;
+        if (g) { t_base = g->inject_pos; if (mode == kSphere && !g->inject) g->event++; }
+    }
+    ~SamplerScope()
+    {
+        ro_rng* g = current_rng();
+        if (g && g->inject) g->inject_pos = t_base + t_calls;
+        t_mode = kBare;
+    }
+};
+} // namespace refinject
+
 namespace pk
 {
-
-bool delay(size_t ms)
-{
-    std::this_thread::sleep_for(std::chrono::milliseconds(ms));
-    return true;
-}
-
-result threadSetName(const char*) { return R_NOTIMPL; }
-
-float random()
-{
-    using namespace refinject;
-    if (t_rng) return ro_random(t_rng);
-    if (t_schedule) return ro_random(scheduled_rng_for_bare_call());
-    static thread_local std::uniform_real_distribution<float> dist(0.0f, 1.0f);
-    return dist(thread_mt());
-}
+vector3 ref_randomInUnitSphere();      // utils.cu:74-83, compiled in ref_utils_wrap.cpp
+vector3 ref_randomOnUnitDisk();        // utils.cu:85-94
 
 vector3 randomInUnitSphere()
 {
-    using namespace refinject;
-    ro_rng* g = t_rng ? t_rng : (t_schedule ? &t_sched_rng : nullptr);
-    if (g) {
-        ro_vec3 p = ro_random_in_unit_sphere(g);
-        return vector3(p.x, p.y, p.z);
-    }
-    vector3      point;
-    unsigned int maxTries = 20;
-    do {
-        float x = random(), y = random(), z = random();
-        point   = 2.0f * vector3(x, y, z) - vector3(1, 1, 1);
-    } while (point.squared_length() >= 1.0f && maxTries--);
-    return point;
+    refinject::SamplerScope scope(refinject::kSphere);
+    return ref_randomInUnitSphere();
 }
 
 vector3 randomOnUnitDisk()
 {
-    using namespace refinject;
-    ro_rng* g = t_rng ? t_rng : (t_schedule ? &t_sched_rng : nullptr);
-    if (g) {
-        ro_vec3 p = ro_random_on_unit_disk(g);
-        return vector3(p.x, p.y, p.z);
-    }
-    vector3      point;
-    unsigned int maxTries = 20;
-    do {
-        float x = random(), y = random();
-        point   = 2.0f * vector3(x, y, 0.0f) - vector3(1.0f, 1.0f, 0.0f);
-    } while (point.dot(point) >= 1.0f && maxTries--);
-    return point;
+    refinject::SamplerScope scope(refinject::kDisk);
+    return ref_randomOnUnitDisk();
 }
-
 } // namespace pk

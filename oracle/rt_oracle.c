@@ -82,6 +82,8 @@ static void rng_block(const ro_rng* g, uint32_t event, uint32_t block, float out
     for (int i = 0; i < 4; ++i) out[i] = ro_u32_to_unit(r[i]);
 }
 
+void ro_rng_block(const ro_rng* g, uint32_t event, uint32_t block, float out[4]) { rng_block(g, event, block, out); }
+
 static float rng_injected(ro_rng* g)
 {
     float v = (g->inject_pos < g->inject_n) ? g->inject[g->inject_pos] : 0.5f;

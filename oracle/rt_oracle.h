@@ -64,6 +64,7 @@ typedef struct {
 
 void    ro_rng_begin_sample(ro_rng* g, uint64_t seed, uint32_t pixel, uint32_t sample);
 void    ro_rng_inject(ro_rng* g, const float* draws, uint32_t n);
+void    ro_rng_block(const ro_rng* g, uint32_t event, uint32_t block, float out[4]);   /* one Philox block of the sample's stream as four uniform floats */
 float   ro_random(ro_rng* g);                   /* utils.cu:65-72 */
 ro_vec3 ro_random_in_unit_sphere(ro_rng* g);    /* utils.cu:74-83 */
 ro_vec3 ro_random_on_unit_disk(ro_rng* g);      /* utils.cu:85-94 */

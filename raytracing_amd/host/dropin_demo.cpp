@@ -1,15 +1,23 @@
-// dropin_demo.cpp -- the drop-in claim, end to end: THE REFERENCE'S OWN scene.h / sphere.h / material.h / camera.h (and its
-// sphere.cpp for the Sphere constructor) next to render_scene_hip.h, exactly as INTEGRATION.md section 2 tells a maintainer
-// to wire the fourth backend in.  Built only where the reference tree exists (oracle/Makefile, target `ref`, output
-// oracle/_ref/dropin_demo); tests/test_gpu_dropin.py runs it on the GPU and compares the framebuffer with the golden frame
-// that the reference's own _renderJob produced.
+// dropin_demo.cpp -- the drop-in claim, end to end: a main() around renderSceneHIP, wired exactly as INTEGRATION.md section 2
+// tells a maintainer to wire the fourth backend in.  One source, two builds:
+//   * the reference-typed build (the oracle's Makefile, target `ref`): against THE REFERENCE'S OWN scene.h / sphere.h / material.h /
+//     camera.h and its sphere.cpp.  Exists only where the reference tree does and never leaves that container: there it
+//     proves that the wrapper compiles and links against the reference's types and fails loudly without a GPU
+//     (tests/test_host_cabi.py).
+//   * raytracing_amd/dropin_twin (csrc/Makefile, target `cli`, -DDROPIN_OWN_TYPES): the same main() against
+//     host/scene_types.h, the own types with the same names and fields.  This one runs on the GPU box, where
+//     tests/test_gpu_dropin.py compares its framebuffer with the golden frames.
 //
 //   dropin_demo <scene.bin> <out.fb.u32> <cols> <rows> <spp> <max_depth> <recursive>
 // scene.bin: uint32 n, then n records of 10 float32: cx cy cz radius type albedo_r albedo_g albedo_b blur ior.
+#ifdef DROPIN_OWN_TYPES
+#include "scene_types.h"
+#else
 #include "camera.h"
 #include "material.h"
 #include "scene.h"
 #include "sphere.h"
+#endif
 
 #include "render_scene_hip.h"
 

@@ -144,3 +144,91 @@ def test_streamed_table_equals_the_oracle(ra, oracle, golden_scenes, monkeypatch
     ctx.render(cols, rows, 0, spp, 50, 21, chunk_spp=spp)
     assert (bits(ctx.read_accum()) == bits(accum)).all()
     ctx.close()
+
+
+def _grazing_view(centre, radius, eye, cols, rows, span_ulps=2.0):
+    """Camera arguments for a zero-aperture view from `eye` along a tangent of the sphere, so narrow that neighbouring
+    pixels are about `span_ulps` float ulps of direction apart: the silhouette crosses the frame and thousands of primary
+    rays have a discriminant b*b - a*c within a few ulps of a(|oc|^2 + r^2) of zero (sphere.cpp:77-79)."""
+    c, e = np.asarray(centre, dtype=np.float64), np.asarray(eye, dtype=np.float64)
+    to_c = c - e
+    dist = np.linalg.norm(to_c)
+    d0 = to_c / dist
+    n = np.cross(d0, [0.0, 1.0, 0.0])
+    if np.linalg.norm(n) < 1e-3:
+        n = np.cross(d0, [1.0, 0.0, 0.0])
+    n /= np.linalg.norm(n)
+    sin_a = radius / dist
+    tangent = np.sqrt(1.0 - sin_a * sin_a) * d0 + sin_a * n
+    length = np.sqrt(dist * dist - radius * radius)
+    look = e + tangent * length                                   # the tangent point
+    vfov = np.degrees(rows * span_ulps * 2.0 ** -24)              # rows pixels of span_ulps * 2^-24 rad each
+    return (np.float32(vfov), np.float32(cols) / np.float32(rows), 0.0, np.float32(length), e.astype(np.float32), (0, 1, 0), look.astype(np.float32))
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -10, 1.0, 37.0, 3.0e4, 1.0e7])
+def test_silhouette_grazing_rays_at_the_filter_margin(ra, oracle, golden_scenes, scale):
+    """Aimed at the filters' margins: views along sphere silhouettes with neighbouring rays ulps apart, at scene scales
+    2^-10 .. 10^7, eyes near and far, both filters, full-scan validation on.  A filter that dropped a grazing hit, or an
+    exact test that resolved one differently from the reference, shows as a filter miss or as a primary-hit map that
+    differs from the oracle's."""
+    s = np.float32(scale)
+    table = golden_scenes["book1"].copy()
+    table[:, 0:4] *= s
+    cols, rows, spp = 192, 128, 1
+    # (sphere index, eye): the big glass and metal balls from the book camera, a small sphere seen from far off-axis, the ground
+    # sphere (r = 1000) from just above it, and a small sphere from an eye almost on its surface
+    views = [(483, (13.0, 2.0, 3.0)), (484, (13.0, 2.0, 3.0)), (100, (300.0, 150.0, -220.0)), (0, (3.0, 0.7, 9.0)),
+             (200, tuple(table[200, 0:3] / s + np.array([0.21, 0.05, 0.02])))]
+    near = 0
+    for kind in (ra.FILTER_MFMA, ra.FILTER_VALU):
+        ctx = ra.Context(0)
+        try:
+            ctx.set_filter(kind)
+            ctx.upload_scene(table)
+            for idx, eye in views:
+                args = _grazing_view(table[idx, 0:3].astype(np.float64), float(table[idx, 3]), np.array(eye, dtype=np.float64) * float(s), cols, rows)
+                ctx.set_camera(ra.Camera(*args))
+                primary, st = ctx.render(cols, rows, 0, spp, 3, 5, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+                accum = ctx.read_accum()
+                assert st["filter_misses"] == 0, (scale, kind, idx, st)
+                o_accum, o_primary, _ = oracle.render(table, oracle.camera(*args), rows, cols, 0, spp, 3, 5, want_primary=True)
+                assert (primary == o_primary).all(), (scale, kind, idx, int((primary != o_primary).sum()))
+                same = (bits(accum) == bits(o_accum)) | (np.isnan(accum) & np.isnan(o_accum))
+                assert same.all()
+                # the silhouette of the aimed-at sphere is inside the frame: both sides of it are populated
+                on = float((primary == idx).mean())
+                if 0.02 < on < 0.98:
+                    near += 1
+        finally:
+            ctx.close()
+    assert near >= 6, near          # most views really straddle their silhouette (the rest are occluded or clipped by rounding)
+
+
+def test_off_axis_sphere_at_the_f16_range_limit(ra, oracle):
+    """The corner the round-1 range guard left open: a sphere at (M, M, M) with M just inside the
+    per-component bound, where a bounce origin on the far side has |o|^2 near 3 M^2 and the per-ray constant of the MFMA
+    filter would overflow f16.  The guard now bounds the norm; glass keeps rays bouncing inside, the full scan checks."""
+    M = np.float32(22.4)
+    rows_ = [[M, M, M, 0.3 * M, ra.MATERIAL_GLASS, 1, 1, 1, 0.0, 1.5],
+             [M, M - 0.31 * M - 1000.0, M, 1000.0, ra.MATERIAL_DIFFUSE, 0.5, 0.5, 0.5, 1.0, 1.0],
+             [M + 0.7 * M, M, M - 0.2 * M, 0.25 * M, ra.MATERIAL_METAL, 0.8, 0.7, 0.6, 0.0, 1.0],
+             [M - 0.5 * M, M + 0.1 * M, M + 0.6 * M, 0.2 * M, ra.MATERIAL_GLASS, 1, 1, 1, 0.0, 1.5]]
+    table = np.array(rows_, dtype=np.float32)
+    cols, rows, spp = 160, 120, 4
+    eye = np.array([M + 1.2 * M, M + 0.3 * M, M + 1.2 * M], dtype=np.float32)
+    args = (40.0, np.float32(cols) / np.float32(rows), 0.0, np.float32(M), eye, (0, 1, 0), (M, M, M))
+    for kind in (ra.FILTER_MFMA, ra.FILTER_VALU):
+        ctx = ra.Context(0)
+        try:
+            ctx.set_filter(kind)
+            ctx.upload_scene(table)
+            ctx.set_camera(ra.Camera(*args))
+            primary, st = ctx.render(cols, rows, 0, spp, 50, 3, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+            accum = ctx.read_accum()
+        finally:
+            ctx.close()
+        assert st["filter_misses"] == 0 and st["rays"] > 2 * st["samples"]      # paths really bounce (the glass ball fills a good part of the frame)
+        o_accum, o_primary, _ = oracle.render(table, oracle.camera(*args), rows, cols, 0, spp, 50, 3, want_primary=True)
+        assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
+        assert float((primary == 0).mean()) > 0.05

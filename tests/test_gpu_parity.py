@@ -79,7 +79,7 @@ def test_recursive_against_oracle(ra, ctx, oracle, golden_scenes, cols, rows, sp
         assert st[k] == o_st[k], k
 
 
-@pytest.mark.parametrize("name", ["book1_120x80_spp1024", "glass_120x80_spp1024", "book1_120x80_spp1024_recursive"])
+@pytest.mark.parametrize("name", ["book1_120x80_spp1024", "glass_120x80_spp1024", "book1_120x80_spp1024_recursive", "scaled_120x80_spp1024"])
 def test_psnr_against_unmodified_reference_render(ra, ctx, oracle, golden_scenes, name):
     """BASELINE's image bar: the unmodified renderScene of the reference (its own mt19937 stream, 1024 spp, fixtures made by
     oracle/gen_fixtures.py / gen_refrenders.py; iterative and -r) and the HIP backend (Philox, 8192 spp) are independent
@@ -95,3 +95,23 @@ def test_psnr_against_unmodified_reference_render(ra, ctx, oracle, golden_scenes
     ctx.render(m["cols"], m["rows"], 0, spp, m["max_depth"], 11, flags=ra.FLAG_RECURSIVE if m.get("recursive") else 0, want_stats=False)
     psnr, rmse = oracle.psnr_rgb8(ctx.resolve(spp), ref)
     assert psnr >= 40.0, (name, psnr, rmse)
+
+
+@pytest.mark.parametrize("scene", ["book1", "glass"])
+def test_benchmark_frame_primary_hits_and_image(ra, ctx, oracle, golden_scenes, scene):
+    """north_star's first bar on the BENCHMARK frame itself: 1200x800, depth 50 -- the sphere index of
+    every primary hit (raytracer.cpp:285-304, lowest index on ties), the colour sums, the counters and the 8-bit
+    framebuffer equal the oracle's, which runs the same 960 000 paths on the host cores."""
+    cols, rows, spp = 1200, 800, 1
+    table = golden_scenes[scene]
+    ctx.upload_scene(table)
+    ctx.set_camera(ra.book_camera(cols, rows))
+    primary, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=spp, want_primary=True)
+    accum = ctx.read_accum()
+    o_accum, o_primary, o_st = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, 0, spp, 50, 1, want_primary=True, nthreads=16)
+    assert (primary == o_primary).all()
+    assert (bits(accum) == bits(o_accum)).all()
+    for k in ("samples", "rays", "sphere_tests", "term_miss", "term_absorb", "term_depth"):
+        assert st[k] == o_st[k], k
+    assert (ctx.resolve(spp) == oracle.resolve(o_accum, rows, cols, spp)).all()
+    assert 0.3 < float((primary != 0xFFFFFFFF).mean()) < 1.0 and len(np.unique(primary)) > 50
