@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--chunk-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true", help="strong scaling (BASELINE's target): --spp is the IMAGE's sample count, split over the ranks by sample index")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and all-reduce even with one rank (rehearsal of the N > 1 path)")
     args = ap.parse_args()
 
@@ -112,14 +113,22 @@ def main():
     ctx.upload_scene(table)
     ctx.set_camera(ra.book_camera(cols, rows))
     accum = TorchAccum(ctx, cols, rows, torch.device("cuda", local_rank))
-    spp_begin = rank * spp                       # weak scaling: rank r owns global samples [r*spp, (r+1)*spp)
+    if args.strong:                              # strong scaling: the image has `spp` samples, rank r traces its share of them
+        from raytracing_amd.multi_gpu import spp_range
+        spp_total = spp
+        spp_begin, spp = spp_range(rank, world, 0, spp_total)
+        if spp == 0:
+            raise SystemExit("bench.py --strong: %d samples cannot feed %d ranks" % (spp_total, world))
+    else:                                        # weak scaling: rank r owns global samples [r*spp, (r+1)*spp)
+        spp_total = spp * world
+        spp_begin = rank * spp
 
     def step():
         ctx.render_async(cols, rows, spp_begin, spp, DEPTH, SEED, 0, args.chunk_spp)
         if use_dist:
             accum.allreduce()
         if rank == 0:
-            ctx.resolve(spp * world)
+            ctx.resolve(spp_total)
         else:
             ctx.sync()
 
@@ -163,8 +172,8 @@ def main():
             "metric": "Msamples/s", "value": round(samples_all / (dt / args.steps) / 1e6, 3), "unit": "Msamples/s",
             "mrays_per_s": round(rays_all / (dt / args.steps) / 1e6, 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "book-1 final scene (seed 1, %d spheres) %dx%d, %d spp per GPU, depth %d" % (len(table), cols, rows, spp, DEPTH),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("book-1 final scene (seed 1, %d spheres) %dx%d, %d spp in all, depth %d" if args.strong else "book-1 final scene (seed 1, %d spheres) %dx%d, %d spp per GPU, depth %d") % (len(table), cols, rows, spp_total if args.strong else spp, DEPTH),
                        "parallelism": "spp split x%d + RCCL all-reduce of the float accumulation buffer" % world if world > 1 else "1 GPU",
                        "rays_per_sample": round(stats["rays"] / stats["samples"], 4)},
             "roofline": {"bound": "mfma", "peak_kind": "FP32 peak (vector = dense f32 MFMA = 157.3 TFLOP/s; BASELINE's north star names the FP32 VALU peak)",

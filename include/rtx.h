@@ -188,6 +188,39 @@ int rtx_load_accum(rtx_ctx* ctx, const char* path, uint32_t* cols, uint32_t* row
  * unpacks).  debug_tile != 0 paints tile borders 0xFF000000 as -d does (raytracer.cpp:168-171). */
 int rtx_resolve_rgbx8(rtx_ctx* ctx, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host);
 
+/* ---- several GPUs of one node (no counterpart in the reference, which is single-device) -------- */
+
+/* A group is one member context per listed device, in ONE process, plus -- for more than one device -- a RCCL communicator
+ * over them (ncclCommInitAll; xGMI inside a node).  The path shards by sample index: member r of R traces the global
+ * samples rtx_spp_range(r, R, ...) of EVERY pixel into its own full-frame accumulation buffer; the Philox counter carries
+ * the global sample index, so the union over members is exactly the one-GPU sample set and primary hits do not depend
+ * on the device count.  rtx_group_allreduce is the one exchange: ncclAllReduce(sum, float32) of rows*cols*3 floats in
+ * place.  Invariant: the SUM over the members' buffers is the image's colour sum -- after the exchange member 0 holds the
+ * total and the others are zeroed, so RTX_FLAG_ACCUMULATE passes and further exchanges count every sample once.
+ * A group of one device is rtx_render bit for bit (its exchange is the identity and RCCL is not initialised).
+ * All calls block.  Members can be tuned individually through rtx_group_member. */
+typedef struct rtx_group rtx_group;
+int rtx_group_create(const int* device_ids, int n_devices, rtx_group** out_group);
+int rtx_group_destroy(rtx_group* group);
+int rtx_group_size(const rtx_group* group);
+rtx_ctx* rtx_group_member(rtx_group* group, int rank);
+int rtx_group_upload_scene(rtx_group* group, uint32_t n,
+                           const float* cx_host, const float* cy_host, const float* cz_host, const float* radius_host,
+                           const uint32_t* mat_type_host,
+                           const float* albedo_r_host, const float* albedo_g_host, const float* albedo_b_host,
+                           const float* blur_host, const float* ior_host);
+int rtx_group_set_camera(rtx_group* group, const rtx_camera* cam);
+/* rtx_render over the group: every member traces its share, all devices side by side.  stats (may be NULL) are summed
+ * over the members, kernel_ms is the slowest member's. */
+int rtx_group_render(rtx_group* group, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                     uint64_t seed, uint32_t flags, uint32_t chunk_spp, rtx_stats* stats);
+int rtx_group_allreduce(rtx_group* group);
+/* rtx_resolve_rgbx8 on member 0 (call rtx_group_allreduce first). */
+int rtx_group_resolve_rgbx8(rtx_group* group, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host);
+/* Contiguous share of [spp_begin, spp_begin + spp_count) of member `rank` of `world`; remainder samples go to the lowest
+ * ranks.  Host arithmetic only: the one-process-per-GPU host (raytracing_amd/multi_gpu.py) splits by the same rule. */
+void rtx_spp_range(uint32_t rank, uint32_t world, uint32_t spp_begin, uint32_t spp_count, uint32_t* begin, uint32_t* count);
+
 /* ---- host-side helpers (no GPU needed) ---------------------------------------------------------------------- */
 
 /* camera.h:20-41: derives the camera from the constructor's arguments, in the constructor's operation order. */

@@ -6,9 +6,9 @@ is its Python host side: a ctypes binding plus a mirror of the reference's opera
 material.h, camera.h).  There is no CPU fallback: without the built library, or without a gfx950 device, rendering
 raises.
 """
-from .api import (Camera, Context, Material, RtxError, Scene, Sphere, Stats, book_camera, lib, random_scene,
-                  render_scene_hip, write_ppm, plan_chunks, MATERIAL_DIFFUSE, MATERIAL_GLASS, MATERIAL_METAL, FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER,
+from .api import (Camera, Context, Group, Material, RtxError, Scene, Sphere, Stats, book_camera, lib, random_scene,
+                  render_scene_hip, write_ppm, plan_chunks, spp_range, MATERIAL_DIFFUSE, MATERIAL_GLASS, MATERIAL_METAL, FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER,
                   FILTER_MFMA, FILTER_VALU)
 
-__all__ = ["Camera", "Context", "Material", "RtxError", "Scene", "Sphere", "Stats", "book_camera", "lib", "random_scene",
-           "render_scene_hip", "write_ppm", "plan_chunks", "MATERIAL_DIFFUSE", "MATERIAL_GLASS", "MATERIAL_METAL", "FLAG_ACCUMULATE", "FLAG_RECURSIVE", "FLAG_VALIDATE_FILTER", "FILTER_MFMA", "FILTER_VALU"]
+__all__ = ["Camera", "Context", "Group", "Material", "RtxError", "Scene", "Sphere", "Stats", "book_camera", "lib", "random_scene",
+           "render_scene_hip", "write_ppm", "plan_chunks", "spp_range", "MATERIAL_DIFFUSE", "MATERIAL_GLASS", "MATERIAL_METAL", "FLAG_ACCUMULATE", "FLAG_RECURSIVE", "FLAG_VALIDATE_FILTER", "FILTER_MFMA", "FILTER_VALU"]

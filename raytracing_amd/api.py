@@ -18,7 +18,8 @@ FILTER_VALU, FILTER_MFMA = 0, 1
 EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_set_camera", "rtx_render",
            "rtx_render_noalloc", "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
            "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks",
-           "rtx_version"]
+           "rtx_version", "rtx_group_create", "rtx_group_destroy", "rtx_group_size", "rtx_group_member", "rtx_group_upload_scene", "rtx_group_set_camera",
+           "rtx_group_render", "rtx_group_allreduce", "rtx_group_resolve_rgbx8", "rtx_spp_range"]
 
 
 class RtxError(RuntimeError):
@@ -105,6 +106,18 @@ def lib():
     L.rtx_write_ppm_p6.argtypes = [C.c_char_p, u32, u32, up]
     L.rtx_save_accum.argtypes = [C.c_void_p, C.c_char_p, u32, u64, u32, u32]
     L.rtx_load_accum.argtypes = [C.c_void_p, C.c_char_p, up, up, up, P(u64), up, up]
+    L.rtx_group_create.argtypes = [P(C.c_int), C.c_int, P(C.c_void_p)]
+    L.rtx_group_destroy.argtypes = [C.c_void_p]
+    L.rtx_group_size.argtypes = [C.c_void_p]
+    L.rtx_group_member.restype = C.c_void_p
+    L.rtx_group_member.argtypes = [C.c_void_p, C.c_int]
+    L.rtx_group_upload_scene.argtypes = [C.c_void_p, u32, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
+    L.rtx_group_set_camera.argtypes = [C.c_void_p, P(CCamera)]
+    L.rtx_group_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, P(Stats)]
+    L.rtx_group_allreduce.argtypes = [C.c_void_p]
+    L.rtx_group_resolve_rgbx8.argtypes = [C.c_void_p, u32, u32, up]
+    L.rtx_spp_range.restype = None
+    L.rtx_spp_range.argtypes = [u32, u32, u32, u32, up, up]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L
@@ -212,14 +225,19 @@ def write_ppm(path, cols, rows, framebuffer, binary=False):
 class Context:
     """One rtx_ctx: one GPU, one stream."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self._h = C.c_void_p()
-        _check(lib().rtx_create(device, C.byref(self._h)))
+        self._owned = _borrowed is None
+        if _borrowed is None:
+            _check(lib().rtx_create(device, C.byref(self._h)))
+        else:
+            self._h = C.c_void_p(_borrowed)          # a member of a Group: the group destroys it
         self.cols = self.rows = 0
 
     def close(self):
         if self._h:
-            lib().rtx_destroy(self._h)
+            if self._owned:
+                lib().rtx_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -321,6 +339,71 @@ class Context:
     def resolve(self, spp_total, debug_tile=0):
         fb = np.zeros(self.cols * self.rows, dtype=np.uint32)
         _check(lib().rtx_resolve_rgbx8(self._h, spp_total, debug_tile, _up(fb)))
+        return fb
+
+
+def spp_range(rank, world, spp_begin, spp_count):
+    """rtx_spp_range: the contiguous share of [spp_begin, spp_begin + spp_count) of `rank` (remainder to the lowest ranks)."""
+    b, c = C.c_uint32(), C.c_uint32()
+    lib().rtx_spp_range(rank, world, spp_begin, spp_count, C.byref(b), C.byref(c))
+    return b.value, c.value
+
+
+class Group:
+    """rtx_group: several GPUs of one node in one process -- samples split by global sample index, one RCCL all-reduce
+    of the accumulation buffers, resolve on member 0."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        _check(lib().rtx_group_create(devs, len(devices), C.byref(self._h)))
+        self.cols = self.rows = 0
+
+    def close(self):
+        if self._h:
+            lib().rtx_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return lib().rtx_group_size(self._h)
+
+    def member(self, rank):
+        h = lib().rtx_group_member(self._h, rank)
+        if not h:
+            raise RtxError(lib().rtx_last_error().decode())
+        m = Context(_borrowed=h)
+        m.cols, m.rows = self.cols, self.rows
+        return m
+
+    def upload_scene(self, table):
+        t = np.ascontiguousarray(np.asarray(table, dtype=np.float32).reshape(-1, 10))
+        cols = [np.ascontiguousarray(t[:, i]) for i in range(10)]
+        mt = np.ascontiguousarray(t[:, 4].astype(np.uint32))
+        _check(lib().rtx_group_upload_scene(self._h, len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), _up(mt),
+                                            _fp(cols[5]), _fp(cols[6]), _fp(cols[7]), _fp(cols[8]), _fp(cols[9])))
+
+    def set_camera(self, cam):
+        c = cam.c if isinstance(cam, Camera) else cam
+        _check(lib().rtx_group_set_camera(self._h, C.byref(c)))
+
+    def render(self, cols, rows, spp_begin, spp_count, max_depth, seed, flags=0, chunk_spp=0, want_stats=True):
+        st = Stats()
+        _check(lib().rtx_group_render(self._h, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, C.byref(st) if want_stats else None))
+        self.cols, self.rows = cols, rows
+        return st.as_dict() if want_stats else None
+
+    def allreduce(self):
+        _check(lib().rtx_group_allreduce(self._h))
+
+    def resolve(self, spp_total, debug_tile=0):
+        fb = np.zeros(self.cols * self.rows, dtype=np.uint32)
+        _check(lib().rtx_group_resolve_rgbx8(self._h, spp_total, debug_tile, _up(fb)))
         return fb
 
 

@@ -2,6 +2,8 @@
 // live in trace_kernel.hip.  No CPU fallback exists: every entry point that renders needs a gfx950 device.
 #include "rtx_device.h"
 
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -757,4 +759,199 @@ extern "C" int rtx_resolve_rgbx8(rtx_ctx* c, uint32_t spp_total, uint32_t debug_
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(framebuffer_host, c->fb, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Several GPUs of one node behind the C ABI: one process, one member context per device, the
+// samples of every pixel split over the members by global sample index, ONE RCCL all-reduce (sum, float32) of the
+// accumulation buffers over xGMI, resolve on member 0.  The reference has no counterpart (it is single-device).
+struct rtx_group {
+    std::vector<rtx_ctx*>   members;
+    std::vector<ncclComm_t> comms;        // empty for a group of one: its all-reduce is the identity
+};
+
+#define NCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) return fail(RTX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// Contiguous share of [spp_begin, spp_begin + spp_count) for member `rank` of `world`; remainder samples go to the lowest
+// ranks (the rule of raytracing_amd/multi_gpu.py spp_range, which the one-process-per-GPU host uses).
+extern "C" void rtx_spp_range(uint32_t rank, uint32_t world, uint32_t spp_begin, uint32_t spp_count, uint32_t* begin, uint32_t* count)
+{
+    if (world == 0) world = 1;
+    const uint32_t base = spp_count / world, rem = spp_count % world;
+    if (count) *count = base + (rank < rem ? 1u : 0u);
+    if (begin) *begin = spp_begin + rank * base + (rank < rem ? rank : rem);
+}
+
+extern "C" int rtx_group_destroy(rtx_group* g)
+{
+    if (!g) return RTX_OK;
+    for (size_t i = 0; i < g->comms.size(); ++i) {
+        if (g->members[i]) (void)hipSetDevice(g->members[i]->device);
+        if (g->comms[i]) (void)ncclCommDestroy(g->comms[i]);
+    }
+    for (rtx_ctx* c : g->members) (void)rtx_destroy(c);
+    delete g;
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_create(const int* device_ids, int n_devices, rtx_group** out)
+{
+    if (!out) return fail(RTX_ERR_ARG, "rtx_group_create: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return fail(RTX_ERR_ARG, "rtx_group_create: need 1..64 device ids");
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < i; ++j)
+            if (device_ids[i] == device_ids[j]) return fail(RTX_ERR_ARG, "rtx_group_create: device %d is listed twice", device_ids[i]);
+    rtx_group* g = new (std::nothrow) rtx_group();
+    if (!g) return fail(RTX_ERR_NOMEM, "rtx_group_create: out of host memory");
+    g->members.assign((size_t)n_devices, nullptr);
+    for (int i = 0; i < n_devices; ++i) {
+        const int rc = rtx_create(device_ids[i], &g->members[(size_t)i]);
+        if (rc) { rtx_group_destroy(g); return rc; }           // rtx_create has set the message
+    }
+    // RTX_GROUP_RCCL=1 makes a group of ONE device go through RCCL too (a communicator of one rank): the rehearsal of the
+    // exchange on a single-GPU box; without it a group of one never touches RCCL
+    const char* force = getenv("RTX_GROUP_RCCL");
+    if (n_devices > 1 || (force && atoi(force) != 0)) {
+        g->comms.assign((size_t)n_devices, nullptr);
+        const ncclResult_t r = ncclCommInitAll(g->comms.data(), n_devices, device_ids);
+        if (r != ncclSuccess) {
+            g->comms.clear();
+            rtx_group_destroy(g);
+            return fail(RTX_ERR_DEVICE, "rtx_group_create: ncclCommInitAll over %d devices failed: %s", n_devices, ncclGetErrorString(r));
+        }
+    }
+    *out = g;
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_size(const rtx_group* g) { return g ? (int)g->members.size() : 0; }
+
+extern "C" rtx_ctx* rtx_group_member(rtx_group* g, int rank)
+{
+    if (!g || rank < 0 || rank >= (int)g->members.size()) { (void)fail(RTX_ERR_ARG, "rtx_group_member: rank out of range"); return nullptr; }
+    return g->members[(size_t)rank];
+}
+
+extern "C" int rtx_group_upload_scene(rtx_group* g, uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius,
+                                      const uint32_t* mat_type, const float* ar, const float* ag, const float* ab, const float* blur, const float* ior)
+{
+    if (!g) return fail(RTX_ERR_ARG, "rtx_group_upload_scene: group is NULL");
+    for (rtx_ctx* c : g->members) {
+        const int rc = rtx_upload_scene(c, n, cx, cy, cz, radius, mat_type, ar, ag, ab, blur, ior);
+        if (rc) return rc;
+    }
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_set_camera(rtx_group* g, const rtx_camera* cam)
+{
+    if (!g) return fail(RTX_ERR_ARG, "rtx_group_set_camera: group is NULL");
+    for (rtx_ctx* c : g->members) {
+        const int rc = rtx_set_camera(c, cam);
+        if (rc) return rc;
+    }
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_render(rtx_group* g, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                                uint64_t seed, uint32_t flags, uint32_t chunk_spp, rtx_stats* stats)
+{
+    if (!g) return fail(RTX_ERR_ARG, "rtx_group_render: group is NULL");
+    if (cols == 0 || rows == 0 || spp_count == 0) return fail(RTX_ERR_ARG, "rtx_group_render: cols, rows and spp_count must be non-zero");
+    const uint32_t world = (uint32_t)g->members.size();
+    // every member first: the launches of all devices run side by side
+    for (uint32_t r = 0; r < world; ++r) {
+        rtx_ctx* c = g->members[r];
+        uint32_t begin = 0, count = 0;
+        rtx_spp_range(r, world, spp_begin, spp_count, &begin, &count);
+        if (c->ev_open) { double dummy; const int rc0 = rtx_last_kernel_ms(c, &dummy); if (rc0) return rc0; }
+        if (count) {
+            const int rc = enqueue_render(c, cols, rows, begin, count, max_depth, seed, flags, chunk_spp, false, stats != nullptr);
+            if (rc) return rc;
+        } else if (!(flags & RTX_FLAG_ACCUMULATE)) {
+            // more devices than samples: this member contributes zeros (it still takes part in the all-reduce)
+            HIP_TRY(hipSetDevice(c->device));
+            if (c->cols != cols || c->rows != rows) HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->accum_borrowed) {
+                if (c->accum_floats != (size_t)cols * rows * 3) return fail(RTX_ERR_STATE, "rtx_group_render: a member's borrowed accumulation buffer has the wrong size");
+            } else {
+                const int rc = ensure(&c->accum, &c->accum_floats, (size_t)cols * rows * 3);
+                if (rc) return rc;
+            }
+            c->cols = cols; c->rows = rows;
+            HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)cols * rows * 3 * sizeof(float), c->stream));
+            if (stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
+        } else if (c->cols != cols || c->rows != rows || !c->accum) {
+            return fail(RTX_ERR_STATE, "rtx_group_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
+        }
+    }
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (uint32_t r = 0; r < world; ++r) {
+        rtx_ctx* c = g->members[r];
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        uint32_t begin = 0, count = 0;
+        rtx_spp_range(r, world, spp_begin, spp_count, &begin, &count);
+        if (!stats || count == 0) continue;
+        double ms = 0.0;
+        const int rc = rtx_last_kernel_ms(c, &ms);
+        if (rc) return rc;
+        if (max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE)) {
+            stats->samples += (uint64_t)cols * rows * count;
+            stats->term_depth += (uint64_t)cols * rows * count;
+        } else {
+            unsigned long long h[kStCount + 12];
+            HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
+            stats->samples += h[kStSamples]; stats->rays += h[kStRays]; stats->sphere_tests += h[kStRays] * (uint64_t)c->n;
+            stats->term_miss += h[kStMiss]; stats->term_absorb += h[kStAbsorb]; stats->term_depth += h[kStDepth];
+            stats->candidates += h[kStCandidates]; stats->filter_misses += h[kStFilterMiss];
+        }
+        stats->kernel_ms = std::max(stats->kernel_ms, ms);       // the members run side by side
+    }
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_allreduce(rtx_group* g)
+{
+    if (!g) return fail(RTX_ERR_ARG, "rtx_group_allreduce: group is NULL");
+    const size_t world = g->members.size();
+    rtx_ctx* c0 = g->members[0];
+    if (!c0->accum || c0->cols == 0) return fail(RTX_ERR_STATE, "rtx_group_allreduce: nothing rendered yet");
+    const size_t count = (size_t)c0->cols * c0->rows * 3;
+    for (rtx_ctx* c : g->members)
+        if (!c->accum || (size_t)c->cols * c->rows * 3 != count) return fail(RTX_ERR_STATE, "rtx_group_allreduce: the members hold images of different sizes");
+    if (g->comms.empty()) return RTX_OK;                         // a group of one: the sum over one buffer
+    // one collective: sum of rows*cols*3 floats (11.5 MB at 1200 x 800, 99.5 MB at 3840 x 2160), in place, each rank's part
+    // on that member's own stream, i.e. behind its trace and reduce kernels
+    NCCL_TRY(ncclGroupStart());
+    for (size_t i = 0; i < world; ++i) {
+        rtx_ctx* c = g->members[i];
+        const ncclResult_t r = ncclAllReduce(c->accum, c->accum, count, ncclFloat32, ncclSum, g->comms[i], c->stream);
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(RTX_ERR_DEVICE, "ncclAllReduce on member %zu failed: %s", i, ncclGetErrorString(r)); }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    // Invariant of a group: the SUM over the members' buffers is the image's colour sum.  After the exchange every member
+    // holds that total, so all but member 0 start again from zero -- a later RTX_FLAG_ACCUMULATE pass and the next
+    // exchange then count every sample once (progressive renders; multi_gpu.render_progressive keeps the same invariant).
+    for (size_t i = 1; i < world; ++i) {
+        rtx_ctx* c = g->members[i];
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemsetAsync(c->accum, 0, count * sizeof(float), c->stream));
+    }
+    for (rtx_ctx* c : g->members) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_resolve_rgbx8(rtx_group* g, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host)
+{
+    if (!g) return fail(RTX_ERR_ARG, "rtx_group_resolve_rgbx8: group is NULL");
+    return rtx_resolve_rgbx8(g->members[0], spp_total, debug_tile, framebuffer_host);
 }

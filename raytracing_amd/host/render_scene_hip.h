@@ -23,7 +23,8 @@ namespace pk
 // Options beyond the reference's signature (all optional; the defaults give the reference's one-shot behaviour).
 struct HipRenderOptions {
     uint64_t    seed = 1;
-    int         device = 0;
+    int         device = 0;              // first GPU
+    int         n_devices = 1;           // GPUs device .. device + n_devices - 1: samples split by index, one RCCL all-reduce per exchange
     rtx_stats*  stats = nullptr;         // counters of the last pass
     unsigned    pass_spp = 0;            // > 0: progressive, this many samples per pass
     const char* checkpoint = nullptr;    // written after every pass (rtx_save_accum)
@@ -59,18 +60,27 @@ inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned row
     cam.lens_radius = camera.lensRadius;
 
     const uint32_t flags = recursive ? RTX_FLAG_RECURSIVE : 0u;
-    rtx_ctx* ctx = nullptr;
-    int rc = rtx_create(opt.device, &ctx);
-    if (rc == RTX_OK) rc = rtx_upload_scene(ctx, (uint32_t)n, cx.data(), cy.data(), cz.data(), rad.data(), type.data(), ar.data(), ag.data(), ab.data(), blur.data(), ior.data());
-    if (rc == RTX_OK) rc = rtx_set_camera(ctx, &cam);
+    // a group of n_devices member contexts; a group of one is a plain context (no RCCL involved)
+    std::vector<int> devs;
+    for (int d = 0; d < (opt.n_devices > 0 ? opt.n_devices : 1); ++d) devs.push_back(opt.device + d);
+    rtx_group* grp = nullptr;
+    int rc = rtx_group_create(devs.data(), (int)devs.size(), &grp);
+    rtx_ctx* ctx = rc == RTX_OK ? rtx_group_member(grp, 0) : nullptr;
+    if (rc == RTX_OK) rc = rtx_group_upload_scene(grp, (uint32_t)n, cx.data(), cy.data(), cz.data(), rad.data(), type.data(), ar.data(), ag.data(), ab.data(), blur.data(), ior.data());
+    if (rc == RTX_OK) rc = rtx_group_set_camera(grp, &cam);
     unsigned done = 0;
     if (rc == RTX_OK && opt.resume && opt.checkpoint) {
+        // the checkpoint is the sum over all devices: it goes to member 0, the others start from zero (first pass below)
         uint32_t c_cols = 0, c_rows = 0, c_done = 0, c_depth = 0, c_flags = 0;
         uint64_t c_seed = 0;
         if (rtx_load_accum(ctx, opt.checkpoint, &c_cols, &c_rows, &c_done, &c_seed, &c_depth, &c_flags) == RTX_OK) {
             if (c_cols == cols && c_rows == rows && c_seed == opt.seed && c_depth == max_ray_depth && c_flags == flags && c_done <= num_aa_samples) {
                 done = c_done;
                 printf("renderSceneHIP: resuming %s at %u of %u samples\n", opt.checkpoint, done, num_aa_samples);
+                if (devs.size() > 1) {
+                    std::vector<float> zeros((size_t)cols * rows * 3, 0.0f);
+                    for (int d = 1; d < (int)devs.size() && rc == RTX_OK; ++d) rc = rtx_write_accum(rtx_group_member(grp, d), cols, rows, zeros.data(), zeros.size());
+                }
             } else {
                 printf("renderSceneHIP: %s belongs to another render (size, seed, depth or -r differ); starting over\n", opt.checkpoint);
             }
@@ -80,28 +90,30 @@ inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned row
     bool go_on = true;
     while (rc == RTX_OK && go_on && done < num_aa_samples) {
         const unsigned count = (num_aa_samples - done < pass) ? num_aa_samples - done : pass;
-        rc = rtx_render(ctx, cols, rows, done, count, max_ray_depth, opt.seed, flags | (done ? RTX_FLAG_ACCUMULATE : 0u), 0, nullptr, opt.stats);
+        rc = rtx_group_render(grp, cols, rows, done, count, max_ray_depth, opt.seed, flags | (done ? RTX_FLAG_ACCUMULATE : 0u), 0, opt.stats);
         if (rc != RTX_OK) break;
         done += count;
-        if (opt.checkpoint) rc = rtx_save_accum(ctx, opt.checkpoint, done, opt.seed, max_ray_depth, flags);
-        if (rc == RTX_OK && (opt.on_pass || done == num_aa_samples)) {
-            rc = rtx_resolve_rgbx8(ctx, done, debug ? blockSize : 0u, frameBuffer);
+        const bool show = opt.on_pass || done == num_aa_samples;
+        if (opt.checkpoint || show) rc = rtx_group_allreduce(grp);        // member 0 now holds the sum over the devices
+        if (rc == RTX_OK && opt.checkpoint) rc = rtx_save_accum(ctx, opt.checkpoint, done, opt.seed, max_ray_depth, flags);
+        if (rc == RTX_OK && show) {
+            rc = rtx_group_resolve_rgbx8(grp, done, debug ? blockSize : 0u, frameBuffer);
             if (rc == RTX_OK && opt.on_pass) go_on = opt.on_pass(frameBuffer, done, opt.user);
         }
     }
-    if (rc == RTX_OK && done == num_aa_samples && opt.resume) rc = rtx_resolve_rgbx8(ctx, done, debug ? blockSize : 0u, frameBuffer);   // resumed a finished render
+    if (rc == RTX_OK && done == num_aa_samples && opt.resume) rc = rtx_group_resolve_rgbx8(grp, done, debug ? blockSize : 0u, frameBuffer);   // resumed a finished render
     if (rc != RTX_OK) printf("renderSceneHIP: %s\n", rtx_last_error());
-    rtx_destroy(ctx);
+    rtx_group_destroy(grp);
     return rc;
 }
 
 // The reference's signature (raytracer.h:17-19) plus trailing defaults.
 inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned rows, unsigned cols, uint32_t* frameBuffer,
                           unsigned num_aa_samples = 4, unsigned max_ray_depth = 50, unsigned numThreads = 1, unsigned blockSize = 64,
-                          bool debug = false, bool recursive = true, uint64_t seed = 1, int device = 0, rtx_stats* stats = nullptr)
+                          bool debug = false, bool recursive = true, uint64_t seed = 1, int device = 0, rtx_stats* stats = nullptr, int n_devices = 1)
 {
     HipRenderOptions opt;
-    opt.seed = seed; opt.device = device; opt.stats = stats;
+    opt.seed = seed; opt.device = device; opt.stats = stats; opt.n_devices = n_devices;
     return renderSceneHIP(scene, camera, rows, cols, frameBuffer, num_aa_samples, max_ray_depth, numThreads, blockSize, debug, recursive, opt);
 }
 

@@ -1,7 +1,7 @@
 // rtx_cli.cpp -- the command line of the reference (RayTracing.cpp:42-180) with the GPU mode added.
 // Keeps -a -b -d -f -m -r -t; adds -g (HIP backend, the default and only renderer here), -w / -h (image size, the
 // reference's COLS / ROWS are compile-time, RayTracing.cpp:23-24), -s (seed), -n book1|glass|scaled (scene variant),
-// -G device, -p <spp per pass> (progressive: the image file is rewritten after every pass), -k <file> (checkpoint of the
+// -G <number of GPUs> (samples split over devices 0 .. N-1, one RCCL all-reduce), -D <first device>, -p <spp per pass> (progressive: the image file is rewritten after every pass), -k <file> (checkpoint of the
 // float accumulation buffer after every pass), -R (resume from the -k file), -6 (binary P6 instead of P3).
 // -c (CUDA) and -i (ISPC) name back ends this build does not contain and are refused.
 #include "scene_types.h"
@@ -73,8 +73,10 @@ int main(int argc, char** argv)
     if (args.cmdOptionExists("-s")) seed = std::stoull(args.getCmdOption("-s"));
     std::string variant = "book1";
     if (args.cmdOptionExists("-n")) variant = args.getCmdOption("-n");
-    int device = 0;
-    if (args.cmdOptionExists("-G")) device = std::stoi(args.getCmdOption("-G"));
+    int gpus = 1, device = 0;
+    if (args.cmdOptionExists("-G")) gpus = std::stoi(args.getCmdOption("-G"));
+    if (args.cmdOptionExists("-D")) device = std::stoi(args.getCmdOption("-D"));
+    if (gpus < 1 || device < 0) { printf("Error: -G needs a positive GPU count and -D a device index.\n"); return -1; }
     unsigned passSpp = 0;
     if (args.cmdOptionExists("-p")) passSpp = (unsigned)std::stoi(args.getCmdOption("-p"));
     std::string checkpoint;
@@ -94,7 +96,7 @@ int main(int argc, char** argv)
     rtx_stats st{};
     struct PassCtx { std::string file; unsigned cols, rows, total; bool binary; } pc{ filename, cols, rows, (unsigned)aaSamples, binary };
     HipRenderOptions opt;
-    opt.seed = seed; opt.device = device; opt.stats = &st; opt.pass_spp = passSpp; opt.resume = resume;
+    opt.seed = seed; opt.device = device; opt.n_devices = gpus; opt.stats = &st; opt.pass_spp = passSpp; opt.resume = resume;
     opt.checkpoint = checkpoint.empty() ? nullptr : checkpoint.c_str();
     opt.user = &pc;
     if (passSpp) opt.on_pass = [](const uint32_t* fb, unsigned done, void* user) -> bool {

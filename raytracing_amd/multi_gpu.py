@@ -11,7 +11,8 @@ import numpy as np
 
 
 def spp_range(rank, world, spp_begin, spp_count):
-    """Contiguous share of [spp_begin, spp_begin+spp_count) for `rank`; remainder samples go to the lowest ranks."""
+    """Contiguous share of [spp_begin, spp_begin+spp_count) for `rank`; remainder samples go to the lowest ranks.
+    (The same rule as librtx's rtx_spp_range, which rtx_group_render splits by; tests/test_host_cabi.py compares them.)"""
     base, rem = divmod(spp_count, world)
     count = base + (1 if rank < rem else 0)
     begin = spp_begin + rank * base + min(rank, rem)

@@ -188,3 +188,22 @@ def test_chunk_plan_properties():
     assert (len(big) - 1) * 3840 * 2160 * 16 < 1 << 30
     with pytest.raises(api.RtxError):
         api.plan_chunks(10, 100, lanes, max_items=99)
+
+
+def test_spp_range_of_the_library_equals_the_python_hosts():
+    """rtx_spp_range (what rtx_group_render splits by) and multi_gpu.spp_range (the one-process-per-GPU host) are one rule."""
+    import raytracing_amd as ra
+    from raytracing_amd.multi_gpu import spp_range
+    for spp, world, begin in [(500, 8, 0), (4096, 8, 0), (10, 4, 3), (3, 8, 0), (1, 1, 9), (7, 3, 100), (500, 7, 11)]:
+        lib_parts = [ra.spp_range(r, world, begin, spp) for r in range(world)]
+        assert lib_parts == [spp_range(r, world, begin, spp) for r in range(world)]
+        assert sum(c for _, c in lib_parts) == spp
+
+
+def test_library_imports_rccl():
+    """The multi-device exchange lives under the C ABI: librtx.so itself imports ncclCommInitAll / ncclAllReduce."""
+    import subprocess
+    from conftest import ROOT
+    out = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "raytracing_amd", "librtx.so")], text=True)
+    for sym in ("ncclAllReduce", "ncclCommInitAll", "ncclGroupStart", "ncclGroupEnd"):
+        assert (" U " + sym) in out, sym
