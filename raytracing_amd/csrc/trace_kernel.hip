@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         wave_lds = lds0;
     }
     __syncthreads();
-    // per wave (kWaveLdsBytes): 64 ray records (o, a | d, -) that the candidate re-test gathers from -- the MFMA filter
+    // per wave (kWaveLdsBytes): 64 ray records in two planes, (o, a) and (d, -), that the candidate re-test gathers from -- the MFMA filter
     // first uses the same 2 KB to hand its per-ray operands around --, 64 result slots, and the candidate queue
     wave_lds += wave * (kWaveLdsBytes / 16u);
     float4* const             rayrec = wave_lds;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     const uint32_t ray = ent >> 26;
                     uint32_t       i   = ent & 0x03FFFFFFu;
                     if (FILTER == kFilterMfma) i ^= 31u;     // (group, word, bit) -> sphere index, see the extraction below
-                    const float4 r0 = rayrec[ray * 2u], r1 = rayrec[ray * 2u + 1u];
+                    const float4 r0 = rayrec[ray], r1 = rayrec[64u + ray];
                     const float4 s  = exact[i < P.n ? i : 0u];
                     const V3    ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
                     const float ra = r0.w;
@@ -361,8 +361,8 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             if (FILTER == kFilterValu) {
                 const float rs = __builtin_amdgcn_rsqf(a) * (1.0f + kEps);
                 const float fx = d.x * rs, fy = d.y * rs, fz = d.z * rs;
-                rayrec[lane * 2u]      = make_float4(o.x, o.y, o.z, a);
-                rayrec[lane * 2u + 1u] = make_float4(d.x, d.y, d.z, 0.0f);
+                rayrec[lane]       = make_float4(o.x, o.y, o.z, a);            // two planes of 16-byte records: a wave's stores and its
+                rayrec[64u + lane] = make_float4(d.x, d.y, d.z, 0.0f);         // in-order reads are then free of bank conflicts (32-byte records: 2-way)
                 for (uint32_t base = 0; base < P.n_pad; base += 32u) {
                     uint32_t m = 0;
 #pragma unroll
@@ -400,15 +400,15 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 const float od = __builtin_fmaf(o.z, fz, __builtin_fmaf(o.y, fy, o.x * fx));
                 const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
                 float4* const xbuf4 = reinterpret_cast<float4*>(xbuf);
-                xbuf4[lane * 2u]      = make_float4(fx, fy, fz, od);
-                xbuf4[lane * 2u + 1u] = make_float4(o.x, o.y, o.z, oo - kGammaRay * oo);      // |o|^2 minus the ray's share of the margin
+                xbuf4[lane]       = make_float4(fx, fy, fz, od);
+                xbuf4[64u + lane] = make_float4(o.x, o.y, o.z, oo - kGammaRay * oo);      // |o|^2 minus the ray's share of the margin
                 const uint32_t hf = lane >> 5, cl = lane & 31u;
                 const float    sg = P.mfma_scale, T = 32768.0f;
                 h8v b0[2], b1[2];
 #pragma unroll
                 for (uint32_t half = 0; half < 2u; ++half) {
                     const uint32_t ray = half * 32u + cl;
-                    const float4   dv = xbuf4[ray * 2u], ov = xbuf4[ray * 2u + 1u];
+                    const float4   dv = xbuf4[ray], ov = xbuf4[64u + ray];
                     const float    gz = sg * __builtin_fmaf(dv.w, dv.z, -ov.z);             // sg (o.d' d'_z - o_z), against 2 sg C_z
                     // first MFMA: hf 0: -2^15 d'x^2, -2^15 d'y^2, constant sg^2 2^-15 (|o|^2' - (o.d')^2);  hf 1: -2^15 d'z^2, -2^16 d'x d'y, 2^15
                     const float x0 = -T * (hf ? dv.z * dv.z : dv.x * dv.x);
@@ -429,8 +429,8 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 const uint4* tabA = reinterpret_cast<const uint4*>(table) + lane;   // tile t, MFMA m: tabA[(2 t + m) * 64]
                 // the operands are in registers: the same 2 KB now take the ray records of the exact re-test (a wave's
                 // LDS accesses complete in order)
-                rayrec[lane * 2u]      = make_float4(o.x, o.y, o.z, a);
-                rayrec[lane * 2u + 1u] = make_float4(d.x, d.y, d.z, 0.0f);
+                rayrec[lane]       = make_float4(o.x, o.y, o.z, a);            // two planes of 16-byte records: a wave's stores and its
+                rayrec[64u + lane] = make_float4(d.x, d.y, d.z, 0.0f);         // in-order reads are then free of bank conflicts (32-byte records: 2-way)
 
                 RTX_STAMP(8);
                 // STREAM: the workgroup's waves copy chunk g + 1 (128 spheres = 4 tiles = 8 KB, 1 KB per glds16) into one half of
