@@ -35,7 +35,11 @@ enum FilterKind { kFilterValu = 0, kFilterMfma = 1 };
 // where the filter's sphere table lives: read through L2 by every wave, resident in LDS, or (MFMA filter) streamed
 // through a double-buffered LDS stage that the waves of a workgroup fill together, 128 spheres at a time
 enum TableMode { kTableGlobal = 0, kTableLds = 1, kTableStream = 2 };
-constexpr uint32_t kStreamStageBytes = 2 * 8192;       // two buffers of one 128-sphere chunk (4 tiles x 2 KB)
+#ifndef RTX_STREAM_GROUPS
+#define RTX_STREAM_GROUPS 2
+#endif
+constexpr uint32_t kStreamGroups = RTX_STREAM_GROUPS;             // 128-sphere groups per staged chunk: one workgroup barrier per chunk
+constexpr uint32_t kStreamStageBytes = 2 * kStreamGroups * 8192;  // two buffers of one chunk (4 tiles x 2 KB per group)
 constexpr uint32_t kMaxLdsSpheres = 2048;              // VALU filter: 16 B/sphere table stays LDS-resident up to here
 #ifndef RTX_MAX_LDS_MFMA
 #define RTX_MAX_LDS_MFMA 1024

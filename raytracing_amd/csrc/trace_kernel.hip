@@ -433,25 +433,28 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 rayrec[64u + lane] = make_float4(d.x, d.y, d.z, 0.0f);         // in-order reads are then free of bank conflicts (32-byte records: 2-way)
 
                 RTX_STAMP(8);
-                // STREAM: the workgroup's waves copy chunk g + 1 (128 spheres = 4 tiles = 8 KB, 1 KB per glds16) into one half of
+                // STREAM: the workgroup's waves copy chunk g + 1 (kStreamGroups x 128 spheres, 8 KB per group, 1 KB per glds16) into one half of
                 // the stage while everybody filters chunk g out of the other half; one barrier per chunk orders both the
                 // "chunk g has landed" and the "chunk g - 1 is no longer read" directions.
                 const uint32_t nwaves     = blockDim.x >> 6;
                 const uint32_t wave_u     = uniform(wave);
                 const uint32_t stage_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)lds0;
-                auto stage_chunk = [&](uint32_t g) {
-                    for (uint32_t u = wave_u; u < 8u; u += nwaves)
-                        glds16(reinterpret_cast<const uint4*>(P.hot_mfma) + ((size_t)g * 8u + u) * 64u + lane, stage_addr + ((g & 1u) << 13) + (u << 10));
+                const uint32_t n_pieces = (P.n_pad_mfma >> 7) * 8u;        // 1 KB pieces of the whole table
+                auto stage_chunk = [&](uint32_t g) {                       // chunk g = kStreamGroups groups = 8 kStreamGroups pieces
+                    for (uint32_t u = wave_u; u < 8u * kStreamGroups; u += nwaves)
+                        if (g * 8u * kStreamGroups + u < n_pieces)
+                            glds16(reinterpret_cast<const uint4*>(P.hot_mfma) + ((size_t)g * 8u * kStreamGroups + u) * 64u + lane, stage_addr + (g & 1u) * (kStreamGroups << 13) + (u << 10));
                 };
                 if (STREAM && P.n_pad_mfma != 0u) stage_chunk(0u);
                 h8v A0_next, A1_next;
                 if (!STREAM) { A0_next = __builtin_bit_cast(h8v, tabA[0]); A1_next = __builtin_bit_cast(h8v, tabA[64]); }
                 for (uint32_t base = 0; base < P.n_pad_mfma; base += 128u) {
-                    const uint4* stage = reinterpret_cast<const uint4*>(lds0) + (((base >> 7) & 1u) << 9) + lane;
-                    if (STREAM) {
+                    const uint32_t grp = base >> 7, chunk = grp / kStreamGroups, gic = grp - chunk * kStreamGroups;      // group in chunk
+                    const uint4* stage = reinterpret_cast<const uint4*>(lds0) + (((chunk & 1u) * kStreamGroups + gic) << 9) + lane;
+                    if (STREAM && gic == 0u) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __syncthreads();
-                        if (base + 128u < P.n_pad_mfma) stage_chunk((base >> 7) + 1u);
+                        if ((chunk + 1u) * kStreamGroups * 128u < P.n_pad_mfma) stage_chunk(chunk + 1u);
                     }
                     uint32_t word[4];
 #pragma unroll
