@@ -61,7 +61,12 @@ enum {
 };
 
 /* Candidate filters in front of the exact sphereHit arithmetic (results are identical; only speed differs). */
-enum { RTX_FILTER_VALU = 0, RTX_FILTER_MFMA = 1 };
+enum { RTX_FILTER_VALU = 0, RTX_FILTER_MFMA = 1,
+       RTX_FILTER_GRID = 2   /* an acceleration structure instead of a filter over the whole list: a uniform grid
+                                over the table, walked per ray; spheres too large for it are tested for every ray.  For large
+                                tables (faster than the MFMA filter from about 1 500 spheres); the linear list of the
+                                reference is RTX_FILTER_MFMA */,
+       RTX_FILTER_AUTO = 3   /* RTX_FILTER_MFMA below 1 536 spheres, RTX_FILTER_GRID from there on */ };
 
 /* Counters gathered inside the kernel with wave ballots (rays = _sceneHit calls, raytracer.cpp:251). */
 typedef struct rtx_stats {
@@ -96,8 +101,9 @@ int rtx_upload_scene(rtx_ctx* ctx, uint32_t n,
                      const float* albedo_r_host, const float* albedo_g_host, const float* albedo_b_host,
                      const float* blur_host, const float* ior_host);
 
-/* Chooses the candidate filter (default RTX_FILTER_MFMA; the environment variable RTX_FILTER=valu|mfma overrides the
- * default at rtx_create).  No counterpart in the reference: both forms feed the same exact sphere.cpp:68-102 test. */
+/* Chooses the candidate filter (default RTX_FILTER_MFMA; the environment variable RTX_FILTER=valu|mfma|grid|auto overrides the
+ * default at rtx_create).  No counterpart in the reference: all forms feed the same exact sphere.cpp:68-102 test and keep the
+ * minimum of (t, index), i.e. the winner of the linear loop of raytracer.cpp:285-304. */
 int rtx_set_filter(rtx_ctx* ctx, int kind);
 
 /* Tuning knobs of the launch (no counterpart in the reference; results do not depend on them except through the order
@@ -111,6 +117,7 @@ int rtx_set_filter(rtx_ctx* ctx, int kind);
  *   "partials_mb"    RTX_PARTIALS_MB     cap of the partial-sum scratch (16 B per chunk and pixel) in MiB (1024)
  *   "wave_batch"     RTX_WAVE_BATCH      work items a wave reserves per trip to the counter; 0 = automatic
  *   "lds_pad"        RTX_LDS_PAD         extra LDS bytes per workgroup (experiments on occupancy)
+ *   "grid_density_pct" RTX_GRID_DENSITY_PCT  RTX_FILTER_GRID: spheres per grid cell x 100 (35); takes effect at the next rtx_upload_scene
  *   "print_phases"   RTX_PRINT_PHASES    diagnostic builds only */
 int rtx_set_tuning(rtx_ctx* ctx, const char* key, int value);
 

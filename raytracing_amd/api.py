@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("RTX_LIB_PATH") or os.path.join(_HERE, "librtx.so")
 
 MATERIAL_NONE, MATERIAL_DIFFUSE, MATERIAL_METAL, MATERIAL_GLASS = 0, 1, 2, 3   # material.h:9-14
 FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER = 1, 2, 4
-FILTER_VALU, FILTER_MFMA = 0, 1
+FILTER_VALU, FILTER_MFMA, FILTER_GRID, FILTER_AUTO = 0, 1, 2, 3
 
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_set_camera", "rtx_render",

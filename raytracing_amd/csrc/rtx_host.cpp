@@ -86,6 +86,105 @@ uint32_t rtx::plan_chunks(uint32_t spp_count, uint64_t npix, uint64_t lanes, uin
     }
 }
 
+// Uniform grid for RTX_FILTER_GRID (an acceleration structure over the SoA table; no counterpart in the
+// reference, whose _sceneHit is the linear loop of raytracer.cpp:285-304).  The grid only decides WHICH spheres a ray is
+// tested against; the test itself stays the exact sphere.cpp:68-102 arithmetic and the winner the minimum of (t, index), so
+// results cannot change as long as no sphere that the ray can hit is skipped.  That is what the construction guarantees:
+//   * a sphere is registered in every cell that its bounding box, grown by `pad`, overlaps; `pad` (2^-12 of the largest
+//     coordinate or extent) is some hundred times the error of the traversal's fp32 arithmetic, so a hit point that the
+//     traversal places in the neighbouring cell is still found there;
+//   * spheres whose box would cover more than an eighth of the cells (at least 8, at most 512: the ground sphere) are not binned
+//     but tested for every ray; the grid is then laid out again over the rest;
+//   * the traversal (trace_kernel.hip) visits the cells a ray crosses in order and stops early only when the closest hit so
+//     far lies more than `pad` before the current cell's exit.
+// Resolution: `per_cell` spheres per cell (tuning key "grid_density_pct", default 0.35: measured flat between 0.125 and 0.5 on
+// the book-1 and 20 164-sphere scenes, profiles/r02c_grid_filter.txt), cells as cubic as the extent allows, at most 256 cells per axis.
+void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius, double per_cell, GridHost* out)
+{
+    GridHost& G = *out;
+    G = GridHost();
+    memset(&G.desc, 0, sizeof(G.desc));
+    std::vector<uint32_t> cand;
+    std::vector<uint8_t>  is_big(n, 0);
+    for (int round = 0; round < 8; ++round) {
+        // bounds of the spheres that are (still) meant for the grid
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+        cand.clear();
+        for (uint32_t i = 0; i < n; ++i) {
+            const double c[3] = { cx[i], cy[i], cz[i] }, r = std::fabs((double)radius[i]);
+            if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(r))) { is_big[i] = 1; continue; }   // the exact test decides
+            if (is_big[i]) continue;
+            cand.push_back(i);
+            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k] - r); hi[k] = std::max(hi[k], c[k] + r); }
+        }
+        if (cand.empty()) break;
+        double ext[3], big_coord = 0.0;
+        for (int k = 0; k < 3; ++k) { ext[k] = hi[k] - lo[k]; big_coord = std::max(big_coord, std::max(std::max(std::fabs(lo[k]), std::fabs(hi[k])), ext[k])); }
+        const double pad = std::max(big_coord * std::ldexp(1.0, -12), 1e-30);
+        for (int k = 0; k < 3; ++k) { lo[k] -= 2.0 * pad; hi[k] += 2.0 * pad; ext[k] = hi[k] - lo[k]; }
+        // cell size: (volume * per_cell / count)^(1/3), but a thin extent is one cell thick and then no longer counts as a dimension
+        double h = std::cbrt(ext[0] * ext[1] * ext[2] * per_cell / (double)cand.size());
+        for (int pass = 0; pass < 3; ++pass) {
+            double vol = per_cell / (double)cand.size();
+            int    dims = 0;
+            for (int k = 0; k < 3; ++k) if (ext[k] > h) { vol *= ext[k]; dims++; }
+            if (dims == 0) break;
+            h = std::pow(vol, 1.0 / dims);
+        }
+        uint32_t dim[3];
+        double   hk[3];
+        for (int k = 0; k < 3; ++k) {
+            dim[k] = (uint32_t)std::min(256.0, std::max(1.0, std::floor(ext[k] / std::max(h, 1e-300))));
+            hk[k]  = ext[k] / dim[k];
+        }
+        // which spheres are too large for this grid?
+        const uint64_t all_cells = (uint64_t)dim[0] * dim[1] * dim[2];
+        const uint64_t kBigCells = std::max<uint64_t>(8, std::min<uint64_t>(512, all_cells / 8));
+        bool changed = false;
+        for (uint32_t i : cand) {
+            const double r = std::fabs((double)radius[i]) + pad;
+            uint64_t cells = 1;
+            for (int k = 0; k < 3; ++k) cells *= (uint64_t)std::min<double>(dim[k], std::floor(2.0 * r / hk[k]) + 2.0);
+            if (cells > kBigCells) { is_big[i] = 1; changed = true; }
+        }
+        if (changed) continue;                    // their removal may shrink the bounds a lot (the ground sphere): again
+        GridDesc& D = G.desc;
+        for (int k = 0; k < 3; ++k) { D.gmin[k] = (float)lo[k]; D.h[k] = (float)hk[k]; D.inv_h[k] = (float)(1.0 / hk[k]); D.dim[k] = dim[k]; }
+        D.pad = (float)pad;
+        const size_t ncells = (size_t)dim[0] * dim[1] * dim[2];
+        G.cell_start.assign(ncells + 1, 0u);
+        auto range = [&](uint32_t i, int k, uint32_t* a, uint32_t* b) {
+            const double c = k == 0 ? cx[i] : (k == 1 ? cy[i] : cz[i]), r = std::fabs((double)radius[i]) + pad;
+            const double ga = (c - r - lo[k]) / hk[k], gb = (c + r - lo[k]) / hk[k];
+            *a = (uint32_t)std::min<double>(dim[k] - 1, std::max(0.0, std::floor(ga)));
+            *b = (uint32_t)std::min<double>(dim[k] - 1, std::max(0.0, std::floor(gb)));
+        };
+        for (int fill = 0; fill < 2; ++fill) {
+            std::vector<uint32_t> cursor;
+            if (fill) {
+                uint32_t run = 0;
+                for (size_t c = 0; c < ncells; ++c) { const uint32_t cnt = G.cell_start[c]; G.cell_start[c] = run; run += cnt; }
+                G.cell_start[ncells] = run;
+                G.items.assign(run, 0u);
+                cursor.assign(G.cell_start.begin(), G.cell_start.end() - 1);
+            }
+            for (uint32_t i : cand) {
+                uint32_t a[3], b[3];
+                for (int k = 0; k < 3; ++k) range(i, k, &a[k], &b[k]);
+                for (uint32_t z = a[2]; z <= b[2]; ++z)
+                    for (uint32_t y = a[1]; y <= b[1]; ++y)
+                        for (uint32_t x = a[0]; x <= b[0]; ++x) {
+                            const size_t c = ((size_t)z * dim[1] + y) * dim[0] + x;
+                            if (fill) G.items[cursor[c]++] = i; else G.cell_start[c]++;
+                        }
+            }
+        }
+        break;
+    }
+    for (uint32_t i = 0; i < n; ++i) if (is_big[i] || G.desc.dim[0] == 0u) G.big.push_back(i);
+    G.desc.n_big = (uint32_t)G.big.size();
+}
+
 extern "C" int rtx_plan_chunks(uint32_t spp_count, uint64_t n_pixels, uint64_t lanes, uint32_t items_per_lane, uint32_t max_chunks,
                                uint32_t tail_factor, uint64_t max_items, uint32_t* starts, uint32_t cap, uint32_t* n_chunks)
 {

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     // (1) stage the filter's sphere table into LDS once per workgroup (16 B per sphere for the VALU filter,
     //     64 B per sphere -- the f16 A operands of 32-sphere tiles, two MFMAs each, plus one spare tile -- for the MFMA filter)
     const float4* table = (FILTER == kFilterMfma) ? P.hot_mfma : P.hot;
-    const uint32_t table_f4 = (FILTER == kFilterMfma) ? (P.n_pad_mfma + 32u) * 4u : P.n_pad;
+    const uint32_t table_f4 = (FILTER == kFilterMfma) ? (P.n_pad_mfma + 32u) * 4u : (FILTER == kFilterGrid ? 0u : P.n_pad);
     // sample-chunk boundaries of this launch (TraceParams::chunk_tab), kChunkTabBytes at the very front of the LDS
     uint32_t* const ctab = reinterpret_cast<uint32_t*>(smem);
     if (P.chunk_spp == 0u)
@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     V3       o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1), acc = mk(0, 0, 0);
     // wave-level counters
     uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0, c_filter_miss = 0, c_cand = 0;
+    uint32_t lane_tests = 0;     // grid filter: exact tests this lane ran (the other filters count candidates per batch, wave-wide)
     uint64_t c_rays = 0;
 
     // -r only: per-lane stack of attenuations in global memory, entry k of this lane at att_stack[k * stack_stride]
@@ -284,7 +285,105 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         const float a = dot(d, d);                                        // sphere.cpp:73
         float       closest = 3.402823466e+38f;                           // FLT_MAX, raytracer.cpp:251
         uint32_t    best = kNoHit;
-        {
+        if constexpr (FILTER == kFilterGrid) {
+            // ---- Uniform grid (host side: rtx_host.cpp, build_grid).  Each lane walks the cells that its own
+            // ray crosses, in order, and runs the exact test of sphere.cpp:72-99 on the spheres registered there; the big list
+            // (spheres too large for the grid: the ground) is tested first, for every ray.  The winner is the minimum of
+            // (t, index) as everywhere else, so the order in which spheres are met does not matter, and a sphere met twice
+            // (it is registered in every cell it overlaps) changes nothing.  The walk stops early only when the closest hit so
+            // far lies more than the registration slack before the exit of the cell just finished: every hit point beyond that
+            // exit lies in a later cell or within the slack of this one's boundary, where its sphere was registered here too.
+            auto test = [&](uint32_t i) {
+                lane_tests++;
+                const float4 s  = P.exact[i];
+                const V3    oc = sub(o, mk(s.x, s.y, s.z));
+                const float bq = dot(oc, d);
+                const float cq = dot(oc, oc) - (s.w * s.w);
+                const float disc = bq * bq - a * cq;
+                if (disc > 0) {
+                    const float sq = sqrtf(disc);
+                    float       t  = (-bq - sq) / a;
+                    if (!(t > 0.001f)) t = (-bq + sq) / a;
+                    if (t > 0.001f && t < 3.402823466e+38f && (t < closest || (t == closest && i < best))) { closest = t; best = i; }
+                }
+            };
+            for (uint32_t k = 0; k < P.grid.n_big; ++k) {
+                const uint32_t i = P.grid_big[k];
+                if (tracing) test(i);
+            }
+            if (P.grid.dim[0] != 0u) {
+                const float inf = __builtin_inff();
+                const float slack_t = 2.0f * P.grid.pad * __builtin_amdgcn_rsqf(a);        // the registration slack as a ray parameter
+                // slab clip of the ray against the grid box; a zero component of d leaves that axis unbounded when the origin is inside
+                float    t_in = 0.0f, t_out = inf;
+                float    tnext[3];
+                int      cell[3], cstep[3];
+                bool     walking = tracing;
+                const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float lo = P.grid.gmin[k], hi = lo + (float)P.grid.dim[k] * P.grid.h[k];
+                    if (dd[k] != 0.0f) {
+                        const float inv = 1.0f / dd[k];
+                        const float ta = (lo - oo[k]) * inv, tb = (hi - oo[k]) * inv;
+                        t_in  = fmaxf(t_in, fminf(ta, tb));
+                        t_out = fminf(t_out, fmaxf(ta, tb));
+                    } else if (oo[k] < lo || oo[k] > hi) {
+                        walking = false;
+                    }
+                }
+                walking = walking && t_in <= t_out;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float p = oo[k] + t_in * dd[k];
+                    int c = (int)floorf((p - P.grid.gmin[k]) * P.grid.inv_h[k]);
+                    c = c < 0 ? 0 : (c >= (int)P.grid.dim[k] ? (int)P.grid.dim[k] - 1 : c);
+                    cell[k]  = c;
+                    cstep[k] = dd[k] > 0.0f ? 1 : (dd[k] < 0.0f ? -1 : 0);
+                    if (dd[k] != 0.0f) {
+                        const float inv = 1.0f / dd[k];
+                        // parameter at which the ray leaves cell c along this axis, from the cell's index (nothing accumulates)
+                        tnext[k] = (P.grid.gmin[k] + (float)(c + (dd[k] > 0.0f ? 1 : 0)) * P.grid.h[k] - oo[k]) * inv;
+                    } else {
+                        tnext[k] = inf;
+                    }
+                }
+                uint32_t it = 0u, it_end = 0u;
+                bool     fresh_cell = true;
+                for (;;) {
+                    const uint64_t wm = __ballot(walking);
+                    if (!wm) break;
+                    if (walking) {
+                        if (fresh_cell) {
+                            const uint32_t c = ((uint32_t)cell[2] * P.grid.dim[1] + (uint32_t)cell[1]) * P.grid.dim[0] + (uint32_t)cell[0];
+                            it = P.grid_start[c]; it_end = P.grid_start[c + 1u];
+                            fresh_cell = false;
+                        }
+                        if (it < it_end) {
+                            test(P.grid_items[it]);
+                            ++it;
+                        } else {
+                            // the cell is done: stop if the closest hit lies safely before its exit, else step to the next cell
+                            const float t_leave = fminf(tnext[0], fminf(tnext[1], tnext[2]));
+                            if (closest + slack_t + closest * 4.0e-6f < t_leave) {
+                                walking = false;
+                            } else {
+                                const int ax = (tnext[0] <= tnext[1] && tnext[0] <= tnext[2]) ? 0 : (tnext[1] <= tnext[2] ? 1 : 2);
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) {
+                                    if (k == ax) {
+                                        cell[k] += cstep[k];
+                                        if (cell[k] < 0 || cell[k] >= (int)P.grid.dim[k] || cstep[k] == 0) walking = false;
+                                        tnext[k] = (P.grid.gmin[k] + (float)(cell[k] + (cstep[k] > 0 ? 1 : 0)) * P.grid.h[k] - oo[k]) * (1.0f / dd[k]);
+                                    }
+                                }
+                                fresh_cell = true;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
             // Candidates of all 64 rays go through one wave-wide queue of (ray lane << 26 | entry) words, so that the
             // exact re-test always runs with full lanes: a batch is 64 queue entries, one per lane, whatever rays they
             // belong to.  The testing lane gathers the ray from its record and folds its result into the ray's slot with
@@ -508,7 +607,9 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 closest = __uint_as_float((uint32_t)(rr >> 32));
                 best    = (uint32_t)rr;
             }
-            RTX_STAMP(3);
+        }
+        RTX_STAMP(3);
+        {
 
             if (VALIDATE) {
                 // debug build of the kernel: the reference's full ascending scan next to the filtered result
@@ -721,6 +822,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
 
     // wave totals -> global statistics
     if (P.stats) {
+        if (FILTER == kFilterGrid && lane_tests) atomicAdd(&P.stats[kStCandidates], (unsigned long long)lane_tests);
         if (lane == 0) {
             atomicAdd(&P.stats[kStSamples], (unsigned long long)c_samples);
             atomicAdd(&P.stats[kStRays], (unsigned long long)c_rays);
@@ -783,6 +885,7 @@ template <int FILTER, int TABLE, bool VAL> static const void* kernel_ptr() { ret
 
 static const void* select_kernel(int filter, int table_mode, bool validate)
 {
+    if (filter == kFilterGrid) return validate ? kernel_ptr<kFilterGrid, kTableGlobal, true>() : kernel_ptr<kFilterGrid, kTableGlobal, false>();
     if (filter == kFilterMfma) {
         if (table_mode == kTableStream) return validate ? kernel_ptr<kFilterMfma, kTableStream, true>() : kernel_ptr<kFilterMfma, kTableStream, false>();
         if (table_mode == kTableLds) return validate ? kernel_ptr<kFilterMfma, kTableLds, true>() : kernel_ptr<kFilterMfma, kTableLds, false>();
@@ -795,7 +898,7 @@ static const void* select_kernel(int filter, int table_mode, bool validate)
 size_t trace_lds_bytes(int filter, int table_mode, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block)
 {
     const bool   lds_table = table_mode == kTableLds;
-    const size_t table = lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 64 : (size_t)n_pad * 16) : (table_mode == kTableStream ? kStreamStageBytes : 0);
+    const size_t table = filter == kFilterGrid ? 0 : (lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 64 : (size_t)n_pad * 16) : (table_mode == kTableStream ? kStreamStageBytes : 0));
     const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
     return kChunkTabBytes + table + exact + (size_t)(block / 64) * kWaveLdsBytes;
 }

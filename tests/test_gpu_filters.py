@@ -18,20 +18,23 @@ def ra():
 def test_filters_never_miss(ra, golden_scenes, scene, cols, rows, spp):
     """RTX_FLAG_VALIDATE_FILTER runs the reference's ascending full scan beside the filtered search for every ray."""
     results = {}
-    for kind in (ra.FILTER_VALU, ra.FILTER_MFMA):
+    for kind in (ra.FILTER_VALU, ra.FILTER_MFMA, ra.FILTER_GRID):
         ctx = ra.Context(0)
         ctx.set_filter(kind)
         ctx.upload_scene(golden_scenes[scene])
         ctx.set_camera(ra.book_camera(cols, rows))
         primary, st = ctx.render(cols, rows, 0, spp, 50, 77, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
         assert st["filter_misses"] == 0, (kind, st)
-        assert st["candidates"] < 0.02 * st["sphere_tests"]       # the filter passes only a small share on to the exact test
+        if kind == ra.FILTER_GRID:
+            assert st["candidates"] < 40 * st["rays"]                 # a few cells' worth of exact tests per ray, whatever the table's size
+        else:
+            assert st["candidates"] < 0.02 * st["sphere_tests"]       # the filter passes only a small share on to the exact test
         results[kind] = (primary, ctx.read_accum(), st)
         ctx.close()
-    (p0, a0, s0), (p1, a1, s1) = results[ra.FILTER_VALU], results[ra.FILTER_MFMA]
-    assert (p0 == p1).all() and (bits(a0) == bits(a1)).all()
+    (p0, a0, s0), (p1, a1, s1), (p2, a2, s2) = results[ra.FILTER_VALU], results[ra.FILTER_MFMA], results[ra.FILTER_GRID]
+    assert (p0 == p1).all() and (bits(a0) == bits(a1)).all() and (p0 == p2).all() and (bits(a0) == bits(a2)).all()
     for k in ("samples", "rays", "term_miss", "term_absorb", "term_depth"):
-        assert s0[k] == s1[k]
+        assert s0[k] == s1[k] == s2[k]
 
 
 def test_far_origins_and_large_offsets(ra, oracle, golden_scenes):
@@ -43,7 +46,7 @@ def test_far_origins_and_large_offsets(ra, oracle, golden_scenes):
     pos = np.array([13, 2, 3], dtype=np.float32) + shift
     cam = ra.Camera(20.0, np.float32(cols) / np.float32(rows), 0.1, 10.0, pos, (0, 1, 0), shift)
     ocam = oracle.camera(20.0, np.float32(cols) / np.float32(rows), 0.1, 10.0, pos, (0, 1, 0), shift)
-    for kind in (ra.FILTER_VALU, ra.FILTER_MFMA):
+    for kind in (ra.FILTER_VALU, ra.FILTER_MFMA, ra.FILTER_GRID):
         ctx = ra.Context(0)
         ctx.set_filter(kind)
         ctx.upload_scene(table)
@@ -181,7 +184,7 @@ def test_silhouette_grazing_rays_at_the_filter_margin(ra, oracle, golden_scenes,
     views = [(483, (13.0, 2.0, 3.0)), (484, (13.0, 2.0, 3.0)), (100, (300.0, 150.0, -220.0)), (0, (3.0, 0.7, 9.0)),
              (200, tuple(table[200, 0:3] / s + np.array([0.21, 0.05, 0.02])))]
     near = 0
-    for kind in (ra.FILTER_MFMA, ra.FILTER_VALU):
+    for kind in (ra.FILTER_MFMA, ra.FILTER_VALU, ra.FILTER_GRID):
         ctx = ra.Context(0)
         try:
             ctx.set_filter(kind)
@@ -202,7 +205,7 @@ def test_silhouette_grazing_rays_at_the_filter_margin(ra, oracle, golden_scenes,
                     near += 1
         finally:
             ctx.close()
-    assert near >= 6, near          # most views really straddle their silhouette (the rest are occluded or clipped by rounding)
+    assert near >= 9, near          # most views really straddle their silhouette (the rest are occluded or clipped by rounding)
 
 
 def test_off_axis_sphere_at_the_f16_range_limit(ra, oracle):
@@ -232,3 +235,100 @@ def test_off_axis_sphere_at_the_f16_range_limit(ra, oracle):
         o_accum, o_primary, _ = oracle.render(table, oracle.camera(*args), rows, cols, 0, spp, 50, 3, want_primary=True)
         assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all()
         assert float((primary == 0).mean()) > 0.05
+
+
+@pytest.mark.parametrize("factor", [2.0 ** -10, 1.0, 3.0e4, 1.0e7])
+def test_grid_filter_scale_sweep_and_big_spheres(ra, oracle, golden_scenes, factor):
+    """RTX_FILTER_GRID: the uniform grid at very different scene sizes, with the ground sphere on the
+    big list, against the oracle bit for bit and with the full-scan validation on; its cell slack is relative to the scene."""
+    table = golden_scenes["scaled"].copy()
+    f = np.float32(factor)
+    table[:, 0:4] *= f
+    cols, rows, spp = 96, 64, 2
+    pos, look = np.array([13, 2, 3], dtype=np.float32) * f, np.zeros(3, dtype=np.float32)
+    args = (20.0, np.float32(cols) / np.float32(rows), np.float32(0.1) * f, np.float32(10.0) * f, pos, (0, 1, 0), look)
+    ctx = ra.Context(0)
+    try:
+        ctx.set_filter(ra.FILTER_GRID)
+        ctx.upload_scene(table)
+        ctx.set_camera(ra.Camera(*args))
+        primary, st = ctx.render(cols, rows, 0, spp, 50, 5, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+        accum = ctx.read_accum()
+    finally:
+        ctx.close()
+    assert st["filter_misses"] == 0
+    assert st["candidates"] < 0.05 * st["sphere_tests"]            # a few dozen exact tests per ray instead of 1601
+    o_accum, o_primary, o_st = oracle.render(table, oracle.camera(*args), rows, cols, 0, spp, 50, 5, want_primary=True)
+    same = (bits(accum) == bits(o_accum)) | (np.isnan(accum) & np.isnan(o_accum))
+    assert (primary == o_primary).all() and same.all()
+    assert st["rays"] == o_st["rays"]
+
+
+def test_grid_filter_degenerate_tables(ra, oracle):
+    """No sphere, one sphere, identical spheres, all spheres huge (nothing fits a grid), a sphere of radius 0 and a NaN centre:
+    the grid filter must agree with the oracle wherever the other filters do."""
+    cols, rows, spp = 48, 32, 2
+    cases = {
+        "empty": np.zeros((0, 10), dtype=np.float32),
+        "one": np.array([[0, 0, 0, 1.5, 1, .5, .5, .5, 1, 1]], dtype=np.float32),
+        "twins": np.array([[0, 0, 0, 1.5, 3, 1, 1, 1, 0, 1.5]] * 5, dtype=np.float32),
+        "huge": np.array([[0, -1000, 0, 1000, 1, .5, .5, .5, 1, 1], [0, 1000.5, 0, 999, 2, .8, .8, .8, 0, 1], [2000, 0, 0, 1990, 3, 1, 1, 1, 0, 1.5]], dtype=np.float32),
+        "zero_radius": np.array([[0, 0, 0, 0.0, 1, .5, .5, .5, 1, 1], [1, 0, 0, 0.5, 2, .5, .5, .5, 0.2, 1], [0, -100.5, 0, 100, 1, .3, .6, .3, 1, 1]], dtype=np.float32),
+    }
+    args = (40.0, np.float32(cols) / np.float32(rows), 0.05, 6.0, np.array([3, 1.5, 5], dtype=np.float32), (0, 1, 0), (0, 0, 0))
+    for name, table in cases.items():
+        ctx = ra.Context(0)
+        try:
+            ctx.set_filter(ra.FILTER_GRID)
+            ctx.upload_scene(table)
+            ctx.set_camera(ra.Camera(*args))
+            primary, st = ctx.render(cols, rows, 0, spp, 50, 9, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+            accum = ctx.read_accum()
+        finally:
+            ctx.close()
+        assert st["filter_misses"] == 0, name
+        o_accum, o_primary, _ = oracle.render(table, oracle.camera(*args), rows, cols, 0, spp, 50, 9, want_primary=True)
+        same = (bits(accum) == bits(o_accum)) | (np.isnan(accum) & np.isnan(o_accum))
+        assert (primary == o_primary).all() and same.all(), name
+
+
+def test_auto_filter_picks_by_table_size(ra, golden_scenes):
+    """RTX_FILTER_AUTO is the MFMA filter below 1536 spheres and the grid from there on: same image either way, and the
+    number of exact tests tells which one ran; the grid's density knob changes the candidate count and nothing else."""
+    cols, rows, spp = 96, 64, 2
+    args = (20.0, np.float32(cols) / np.float32(rows), 0.1, 10.0, (13, 2, 3), (0, 1, 0), (0, 0, 0))
+
+    def run(table, kind, density=None):
+        ctx = ra.Context(0)
+        try:
+            ctx.set_filter(kind)
+            if density is not None:
+                ctx.set_tuning("grid_density_pct", density)
+            ctx.upload_scene(table)
+            ctx.set_camera(ra.Camera(*args))
+            _, st = ctx.render(cols, rows, 0, spp, 50, 3, chunk_spp=spp)
+            return ctx.read_accum(), st
+        finally:
+            ctx.close()
+
+    for name, expect in (("book1", ra.FILTER_MFMA), ("scaled", ra.FILTER_GRID)):
+        table = golden_scenes[name]
+        assert (len(table) >= 1536) == (expect == ra.FILTER_GRID)
+        a_auto, s_auto = run(table, ra.FILTER_AUTO)
+        a_ref, s_ref = run(table, expect)
+        other = ra.FILTER_GRID if expect == ra.FILTER_MFMA else ra.FILTER_MFMA
+        a_other, s_other = run(table, other)
+        assert (bits(a_auto) == bits(a_ref)).all() and (bits(a_auto) == bits(a_other)).all()
+        assert s_auto["candidates"] == s_ref["candidates"] != s_other["candidates"]
+    table = golden_scenes["scaled"]
+    a_coarse, s_coarse = run(table, ra.FILTER_GRID, density=400)
+    a_fine, s_fine = run(table, ra.FILTER_GRID, density=12)
+    assert (bits(a_coarse) == bits(a_fine)).all() and s_coarse["candidates"] > s_fine["candidates"]
+    ctx = ra.Context(0)
+    try:
+        with pytest.raises(Exception):
+            ctx.set_tuning("grid_density_pct", 0)
+        with pytest.raises(Exception):
+            ctx.set_filter(4)
+    finally:
+        ctx.close()

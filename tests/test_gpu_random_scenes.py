@@ -1,6 +1,6 @@
 """Randomised parity: small random scenes (overlapping spheres, tiny and huge radii, all three materials, cameras inside
-spheres, zero aperture) through the HIP backend and the oracle must agree bit for bit, with both candidate filters and with
-zero filter misses.  Needs an MI355X."""
+spheres, zero aperture) through the HIP backend and the oracle must agree bit for bit, with all three candidate filters
+(VALU, MFMA, uniform grid) and with zero filter misses.  Needs an MI355X."""
 import numpy as np
 import pytest
 
@@ -48,7 +48,7 @@ def test_random_scene_matches_oracle(ra, oracle, case):
     cam, ocam = ra.Camera(*args), oracle.camera(*args)
     rec = bool(case % 5 == 4)
     o_accum, o_primary, o_st = oracle.render(table, ocam, rows, cols, 0, spp, depth, 77 + case, chunk_spp=spp, recursive=rec, want_primary=True)
-    for kind in (ra.FILTER_MFMA, ra.FILTER_VALU):
+    for kind in (ra.FILTER_MFMA, ra.FILTER_VALU, ra.FILTER_GRID):
         ctx = ra.Context(0)
         try:
             ctx.set_filter(kind)
