@@ -64,9 +64,9 @@ enum {
 enum { RTX_FILTER_VALU = 0, RTX_FILTER_MFMA = 1,
        RTX_FILTER_GRID = 2   /* an acceleration structure instead of a filter over the whole list: a uniform grid
                                 over the table, walked per ray; spheres too large for it are tested for every ray.  For large
-                                tables (faster than the MFMA filter from about 1 500 spheres); the linear list of the
+                                tables (faster than the MFMA filter from about 750 spheres); the linear list of the
                                 reference is RTX_FILTER_MFMA */,
-       RTX_FILTER_AUTO = 3   /* RTX_FILTER_MFMA below 1 536 spheres, RTX_FILTER_GRID from there on */ };
+       RTX_FILTER_AUTO = 3   /* RTX_FILTER_MFMA below 768 spheres, RTX_FILTER_GRID from there on */ };
 
 /* Counters gathered inside the kernel with wave ballots (rays = _sceneHit calls, raytracer.cpp:251). */
 typedef struct rtx_stats {
@@ -248,6 +248,21 @@ int rtx_random_scene(uint64_t seed, int grid_half, float p_diffuse, float p_meta
  * geometrically to the size that gives every lane `items_per_lane` items: only the END of a launch needs small items. */
 int rtx_plan_chunks(uint32_t spp_count, uint64_t n_pixels, uint64_t lanes, uint32_t items_per_lane, uint32_t max_chunks,
                     uint32_t tail_factor, uint64_t max_items, uint32_t* starts, uint32_t cap, uint32_t* n_chunks);
+
+/* The uniform grid of RTX_FILTER_GRID as a pure function (no GPU, no counterpart in the reference; for tests and inspection):
+ * what rtx_upload_scene builds for these spheres at `density_pct` spheres per cell x 100.  info is always filled; the arrays
+ * are filled when non-NULL and large enough (cell_start: dim[0]*dim[1]*dim[2] + 1 entries, items: n_items, big: n_big), else
+ * RTX_ERR_ARG.  Cell (x, y, z) = index (z*dim[1] + y)*dim[0] + x holds the spheres items[cell_start[c] .. cell_start[c+1]). */
+typedef struct rtx_grid_info {
+    float    gmin[3], inv_h[3], h[3];
+    uint32_t dim[3];
+    float    pad;
+    uint32_t n_big;
+    uint64_t n_items;
+} rtx_grid_info;
+int rtx_build_grid(uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius, uint32_t density_pct,
+                   rtx_grid_info* info, uint32_t* cell_start, uint64_t cell_start_cap, uint32_t* items, uint64_t items_cap,
+                   uint32_t* big, uint64_t big_cap);
 
 /* RayTracing.cpp:152-165: "P3\n<cols> <rows>\n255\n" then "r g b\n" per pixel. */
 int rtx_write_ppm(const char* path, uint32_t cols, uint32_t rows, const uint32_t* framebuffer_host);

@@ -7,8 +7,8 @@ material.h, camera.h).  There is no CPU fallback: without the built library, or 
 raises.
 """
 from .api import (Camera, Context, Group, Material, RtxError, Scene, Sphere, Stats, book_camera, lib, random_scene,
-                  render_scene_hip, write_ppm, plan_chunks, spp_range, MATERIAL_DIFFUSE, MATERIAL_GLASS, MATERIAL_METAL, FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER,
+                  render_scene_hip, write_ppm, plan_chunks, build_grid, spp_range, MATERIAL_DIFFUSE, MATERIAL_GLASS, MATERIAL_METAL, FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER,
                   FILTER_MFMA, FILTER_VALU, FILTER_GRID, FILTER_AUTO)
 
 __all__ = ["Camera", "Context", "Group", "Material", "RtxError", "Scene", "Sphere", "Stats", "book_camera", "lib", "random_scene",
-           "render_scene_hip", "write_ppm", "plan_chunks", "spp_range", "MATERIAL_DIFFUSE", "MATERIAL_GLASS", "MATERIAL_METAL", "FLAG_ACCUMULATE", "FLAG_RECURSIVE", "FLAG_VALIDATE_FILTER", "FILTER_MFMA", "FILTER_VALU", "FILTER_GRID", "FILTER_AUTO"]
+           "render_scene_hip", "write_ppm", "plan_chunks", "build_grid", "spp_range", "MATERIAL_DIFFUSE", "MATERIAL_GLASS", "MATERIAL_METAL", "FLAG_ACCUMULATE", "FLAG_RECURSIVE", "FLAG_VALIDATE_FILTER", "FILTER_MFMA", "FILTER_VALU", "FILTER_GRID", "FILTER_AUTO"]

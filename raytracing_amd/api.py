@@ -17,7 +17,7 @@ FILTER_VALU, FILTER_MFMA, FILTER_GRID, FILTER_AUTO = 0, 1, 2, 3
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_set_camera", "rtx_render",
            "rtx_render_noalloc", "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
-           "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks",
+           "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks", "rtx_build_grid",
            "rtx_version", "rtx_group_create", "rtx_group_destroy", "rtx_group_size", "rtx_group_member", "rtx_group_upload_scene", "rtx_group_set_camera",
            "rtx_group_render", "rtx_group_allreduce", "rtx_group_resolve_rgbx8", "rtx_spp_range"]
 
@@ -39,6 +39,12 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class GridInfo(C.Structure):
+    """rtx_grid_info: the uniform grid of FILTER_GRID (rtx_build_grid)."""
+    _fields_ = [("gmin", C.c_float * 3), ("inv_h", C.c_float * 3), ("h", C.c_float * 3), ("dim", C.c_uint32 * 3),
+                ("pad", C.c_float), ("n_big", C.c_uint32), ("n_items", C.c_uint64)]
 
 
 _lib = None
@@ -102,6 +108,7 @@ def lib():
     L.rtx_scene_capacity.argtypes = [C.c_int]
     L.rtx_random_scene.argtypes = [u64, C.c_int, f32, f32, up, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
     L.rtx_plan_chunks.argtypes = [u32, u64, u64, u32, u32, u32, u64, up, u32, up]
+    L.rtx_build_grid.argtypes = [u32, fp, fp, fp, fp, u32, P(GridInfo), up, u64, up, u64, up, u64]
     L.rtx_write_ppm.argtypes = [C.c_char_p, u32, u32, up]
     L.rtx_write_ppm_p6.argtypes = [C.c_char_p, u32, u32, up]
     L.rtx_save_accum.argtypes = [C.c_void_p, C.c_char_p, u32, u64, u32, u32]
@@ -211,6 +218,24 @@ def plan_chunks(spp_count, n_pixels, lanes, items_per_lane=256, max_chunks=63, t
     n = C.c_uint32(0)
     _check(lib().rtx_plan_chunks(spp_count, n_pixels, lanes, items_per_lane, max_chunks, tail_factor, max_items, _up(starts), 64, C.byref(n)))
     return starts[:n.value + 1].copy()
+
+
+def build_grid(table, density_pct=35):
+    """The uniform grid that upload_scene builds for FILTER_GRID (rtx_build_grid; host arithmetic only): a dict with gmin, h,
+    inv_h, dim, pad and the arrays cell_start, items, big."""
+    t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1, 10)
+    cols = [np.ascontiguousarray(t[:, k]) for k in range(4)]
+    info = GridInfo()
+    null = C.POINTER(C.c_uint32)()
+    _check(lib().rtx_build_grid(len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), density_pct, C.byref(info), null, 0, null, 0, null, 0))
+    ncell = int(info.dim[0]) * int(info.dim[1]) * int(info.dim[2])
+    cell_start = np.zeros(ncell + 1, dtype=np.uint32)
+    items = np.zeros(max(1, info.n_items), dtype=np.uint32)
+    big = np.zeros(max(1, info.n_big), dtype=np.uint32)
+    _check(lib().rtx_build_grid(len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), density_pct, C.byref(info),
+                                _up(cell_start), cell_start.size, _up(items), items.size, _up(big), big.size))
+    return {"gmin": np.array(info.gmin[:], dtype=np.float32), "h": np.array(info.h[:], dtype=np.float32), "inv_h": np.array(info.inv_h[:], dtype=np.float32),
+            "dim": np.array(info.dim[:], dtype=np.int64), "pad": float(info.pad), "cell_start": cell_start, "items": items[:info.n_items], "big": big[:info.n_big]}
 
 
 def write_ppm(path, cols, rows, framebuffer, binary=False):

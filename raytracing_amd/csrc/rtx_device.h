@@ -32,7 +32,7 @@ constexpr double   kMfmaAbsMargin = 0.03125;                         // 2^-5
 constexpr float    kGammaRay   = 1.52587890625e-05f * 1.0625f;   // 2^-16 plus room for the rounding of |o|^2 itself
 constexpr double   kGammaSphere = 1.52587890625e-05;
 enum FilterKind { kFilterValu = 0, kFilterMfma = 1, kFilterGrid = 2, kFilterAuto = 3 };   // kFilterAuto is a host-side choice, never a kernel variant
-constexpr uint32_t kAutoGridSpheres = 1536u;
+constexpr uint32_t kAutoGridSpheres = 768u;
 // where the filter's sphere table lives: read through L2 by every wave, resident in LDS, or (MFMA filter) streamed
 // through a double-buffered LDS stage that the waves of a workgroup fill together, 128 spheres at a time
 enum TableMode { kTableGlobal = 0, kTableLds = 1, kTableStream = 2 };
@@ -54,8 +54,9 @@ struct TraceParams {
     const float4* hot_mfma; // (n_pad_mfma/32 + 1) tiles x 2 MFMAs x 64 lanes x 16 B: f16 A operands (ten monomials per sphere) of the MFMA filter
     uint32_t      n_pad_mfma;
     float         mfma_scale; // power of two applied to the sphere side of the MFMA filter (f16 range)
-    GridDesc      grid;       // RTX_FILTER_GRID: uniform grid over the table (rtx_plan.h); cell c holds grid_items[grid_start[c] .. grid_start[c+1])
-    const uint32_t* grid_start;
+    GridDesc      grid;       // RTX_FILTER_GRID: uniform grid over the table (rtx_plan.h); cell c holds the entries [grid_range[c].x, grid_range[c].y) of grid_geom (centre, radius: a copy, so that a test is one load behind the cell's) / grid_items (sphere index)
+    const uint2*    grid_range;
+    const float4*   grid_geom;
     const uint32_t* grid_items;
     const uint32_t* grid_big;  // grid.n_big spheres tested for every ray
     const float4* exact;    // n x (cx, cy, cz, r)                   -- sphere.h:24-28 geometry, as uploaded

@@ -185,6 +185,21 @@ void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* 
     G.desc.n_big = (uint32_t)G.big.size();
 }
 
+extern "C" int rtx_build_grid(uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius, uint32_t density_pct,
+                              rtx_grid_info* info, uint32_t* cell_start, uint64_t cell_start_cap, uint32_t* items, uint64_t items_cap,
+                              uint32_t* big, uint64_t big_cap)
+{
+    if (!info || (n && !(cx && cy && cz && radius)) || density_pct < 1 || density_pct > 6400) return RTX_ERR_ARG;
+    rtx::GridHost G;
+    rtx::build_grid(n, cx, cy, cz, radius, density_pct / 100.0, &G);
+    for (int k = 0; k < 3; ++k) { info->gmin[k] = G.desc.gmin[k]; info->inv_h[k] = G.desc.inv_h[k]; info->h[k] = G.desc.h[k]; info->dim[k] = G.desc.dim[k]; }
+    info->pad = G.desc.pad; info->n_big = G.desc.n_big; info->n_items = G.items.size();
+    if (cell_start) { if (cell_start_cap < G.cell_start.size()) return RTX_ERR_ARG; std::copy(G.cell_start.begin(), G.cell_start.end(), cell_start); }
+    if (items)      { if (items_cap < G.items.size()) return RTX_ERR_ARG; std::copy(G.items.begin(), G.items.end(), items); }
+    if (big)        { if (big_cap < G.big.size()) return RTX_ERR_ARG; std::copy(G.big.begin(), G.big.end(), big); }
+    return RTX_OK;
+}
+
 extern "C" int rtx_plan_chunks(uint32_t spp_count, uint64_t n_pixels, uint64_t lanes, uint32_t items_per_lane, uint32_t max_chunks,
                                uint32_t tail_factor, uint64_t max_items, uint32_t* starts, uint32_t cap, uint32_t* n_chunks)
 {

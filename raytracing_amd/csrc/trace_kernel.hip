@@ -125,7 +125,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
 }
 
 template <int FILTER, int TABLE, bool VALIDATE>
-__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(4))) trace_kernel(const TraceParams P)   // <= 128 VGPRs
+__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(FILTER == kFilterGrid ? 6 : 4))) trace_kernel(const TraceParams P)   // <= 128 VGPRs; the grid walk hides its dependent loads better with 6 waves of <= 80 (36.6 -> 32.3 ms at 20 164 spheres; 8 waves spill)
 {
     constexpr bool LDS_TABLE = (TABLE == kTableLds);
     constexpr bool STREAM    = (TABLE == kTableStream);
@@ -293,9 +293,9 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             // (it is registered in every cell it overlaps) changes nothing.  The walk stops early only when the closest hit so
             // far lies more than the registration slack before the exit of the cell just finished: every hit point beyond that
             // exit lies in a later cell or within the slack of this one's boundary, where its sphere was registered here too.
-            auto test = [&](uint32_t i) {
+            // sphere.cpp:72-99 on geometry s; the sphere's index is only needed when the hit could become the closest one
+            auto test = [&](const float4 s, auto index) {
                 lane_tests++;
-                const float4 s  = P.exact[i];
                 const V3    oc = sub(o, mk(s.x, s.y, s.z));
                 const float bq = dot(oc, d);
                 const float cq = dot(oc, oc) - (s.w * s.w);
@@ -304,28 +304,30 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     const float sq = sqrtf(disc);
                     float       t  = (-bq - sq) / a;
                     if (!(t > 0.001f)) t = (-bq + sq) / a;
-                    if (t > 0.001f && t < 3.402823466e+38f && (t < closest || (t == closest && i < best))) { closest = t; best = i; }
+                    if (t > 0.001f && t < 3.402823466e+38f && t <= closest) {
+                        const uint32_t i = index();
+                        if (t < closest || i < best) { closest = t; best = i; }
+                    }
                 }
             };
             for (uint32_t k = 0; k < P.grid.n_big; ++k) {
                 const uint32_t i = P.grid_big[k];
-                if (tracing) test(i);
+                if (tracing) test(P.exact[i], [&] { return i; });
             }
             if (P.grid.dim[0] != 0u) {
                 const float inf = __builtin_inff();
                 const float slack_t = 2.0f * P.grid.pad * __builtin_amdgcn_rsqf(a);        // the registration slack as a ray parameter
                 // slab clip of the ray against the grid box; a zero component of d leaves that axis unbounded when the origin is inside
                 float    t_in = 0.0f, t_out = inf;
-                float    tnext[3];
-                int      cell[3], cstep[3];
                 bool     walking = tracing;
                 const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+                float    inv[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float lo = P.grid.gmin[k], hi = lo + (float)P.grid.dim[k] * P.grid.h[k];
+                    inv[k] = 1.0f / dd[k];
                     if (dd[k] != 0.0f) {
-                        const float inv = 1.0f / dd[k];
-                        const float ta = (lo - oo[k]) * inv, tb = (hi - oo[k]) * inv;
+                        const float ta = (lo - oo[k]) * inv[k], tb = (hi - oo[k]) * inv[k];
                         t_in  = fmaxf(t_in, fminf(ta, tb));
                         t_out = fminf(t_out, fmaxf(ta, tb));
                     } else if (oo[k] < lo || oo[k] > hi) {
@@ -333,52 +335,58 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
                 walking = walking && t_in <= t_out;
+                // Per axis: tn = parameter at which the ray leaves its current cell, dt = parameter per cell, the signed step of the
+                // linear cell index, and (10 bits each, packed in `rem`) how many cells are left before the ray leaves the grid.
+                // tn accumulates one rounding per step: at most 768 steps x 2^-24 of the largest parameter, a third of the
+                // registration pad (2^-12 of the extent), whose double is what the early stop leaves as slack.
+                float    tn[3], dt[3];
+                int      cstride[3];
+                uint32_t rem = 0u, cidx = 0u;
+                const uint32_t stride[3] = { 1u, P.grid.dim[0], P.grid.dim[0] * P.grid.dim[1] };
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float p = oo[k] + t_in * dd[k];
                     int c = (int)floorf((p - P.grid.gmin[k]) * P.grid.inv_h[k]);
                     c = c < 0 ? 0 : (c >= (int)P.grid.dim[k] ? (int)P.grid.dim[k] - 1 : c);
-                    cell[k]  = c;
-                    cstep[k] = dd[k] > 0.0f ? 1 : (dd[k] < 0.0f ? -1 : 0);
+                    cidx += (uint32_t)c * stride[k];
+                    const bool fwd = dd[k] > 0.0f;
                     if (dd[k] != 0.0f) {
-                        const float inv = 1.0f / dd[k];
-                        // parameter at which the ray leaves cell c along this axis, from the cell's index (nothing accumulates)
-                        tnext[k] = (P.grid.gmin[k] + (float)(c + (dd[k] > 0.0f ? 1 : 0)) * P.grid.h[k] - oo[k]) * inv;
+                        tn[k] = (P.grid.gmin[k] + (float)(c + (fwd ? 1 : 0)) * P.grid.h[k] - oo[k]) * inv[k];
+                        dt[k] = P.grid.h[k] * __builtin_fabsf(inv[k]);
+                        rem  |= (uint32_t)(fwd ? (int)P.grid.dim[k] - 1 - c : c) << (10 * k);
                     } else {
-                        tnext[k] = inf;
+                        tn[k] = inf;
+                        dt[k] = 0.0f;
                     }
+                    cstride[k] = fwd ? (int)stride[k] : -(int)stride[k];
                 }
                 uint32_t it = 0u, it_end = 0u;
                 bool     fresh_cell = true;
                 for (;;) {
-                    const uint64_t wm = __ballot(walking);
-                    if (!wm) break;
-                    if (walking) {
-                        if (fresh_cell) {
-                            const uint32_t c = ((uint32_t)cell[2] * P.grid.dim[1] + (uint32_t)cell[1]) * P.grid.dim[0] + (uint32_t)cell[0];
-                            it = P.grid_start[c]; it_end = P.grid_start[c + 1u];
-                            fresh_cell = false;
-                        }
-                        if (it < it_end) {
-                            test(P.grid_items[it]);
-                            ++it;
+                    if (!__ballot(walking)) break;
+                    if (walking && fresh_cell) {
+                        const uint2 range = P.grid_range[cidx];
+                        it = range.x; it_end = range.y;
+                        fresh_cell = false;
+                    }
+                    if (walking && it < it_end) {
+                        test(P.grid_geom[it], [&] { return P.grid_items[it]; });
+                        ++it;
+                    }
+                    if (walking && it >= it_end) {
+                        // the cell is done: stop if the closest hit lies safely before its exit, else step to the next cell
+                        const float t_leave = fminf(tn[0], fminf(tn[1], tn[2]));
+                        const bool  ax0 = tn[0] <= tn[1] && tn[0] <= tn[2], ax1 = !ax0 && tn[1] <= tn[2];
+                        const uint32_t sh = ax0 ? 0u : (ax1 ? 10u : 20u);
+                        if (closest + slack_t + closest * 4.0e-6f < t_leave || ((rem >> sh) & 1023u) == 0u) {
+                            walking = false;
                         } else {
-                            // the cell is done: stop if the closest hit lies safely before its exit, else step to the next cell
-                            const float t_leave = fminf(tnext[0], fminf(tnext[1], tnext[2]));
-                            if (closest + slack_t + closest * 4.0e-6f < t_leave) {
-                                walking = false;
-                            } else {
-                                const int ax = (tnext[0] <= tnext[1] && tnext[0] <= tnext[2]) ? 0 : (tnext[1] <= tnext[2] ? 1 : 2);
-#pragma unroll
-                                for (int k = 0; k < 3; ++k) {
-                                    if (k == ax) {
-                                        cell[k] += cstep[k];
-                                        if (cell[k] < 0 || cell[k] >= (int)P.grid.dim[k] || cstep[k] == 0) walking = false;
-                                        tnext[k] = (P.grid.gmin[k] + (float)(cell[k] + (cstep[k] > 0 ? 1 : 0)) * P.grid.h[k] - oo[k]) * (1.0f / dd[k]);
-                                    }
-                                }
-                                fresh_cell = true;
-                            }
+                            rem  -= 1u << sh;
+                            cidx += (uint32_t)(ax0 ? cstride[0] : (ax1 ? cstride[1] : cstride[2]));
+                            tn[0] += ax0 ? dt[0] : 0.0f;
+                            tn[1] += ax1 ? dt[1] : 0.0f;
+                            tn[2] += (ax0 || ax1) ? 0.0f : dt[2];
+                            fresh_cell = true;
                         }
                     }
                 }

@@ -25,6 +25,7 @@ struct HipRenderOptions {
     uint64_t    seed = 1;
     int         device = 0;              // first GPU
     int         n_devices = 1;           // GPUs device .. device + n_devices - 1: samples split by index, one RCCL all-reduce per exchange
+    int         filter = -1;             // RTX_FILTER_* for the candidate search; -1 keeps the library's default (RTX_FILTER / the linear list through the MFMA filter)
     rtx_stats*  stats = nullptr;         // counters of the last pass
     unsigned    pass_spp = 0;            // > 0: progressive, this many samples per pass
     const char* checkpoint = nullptr;    // written after every pass (rtx_save_accum)
@@ -66,6 +67,7 @@ inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned row
     rtx_group* grp = nullptr;
     int rc = rtx_group_create(devs.data(), (int)devs.size(), &grp);
     rtx_ctx* ctx = rc == RTX_OK ? rtx_group_member(grp, 0) : nullptr;
+    for (int d = 0; d < (int)devs.size() && rc == RTX_OK && opt.filter >= 0; ++d) rc = rtx_set_filter(rtx_group_member(grp, d), opt.filter);
     if (rc == RTX_OK) rc = rtx_group_upload_scene(grp, (uint32_t)n, cx.data(), cy.data(), cz.data(), rad.data(), type.data(), ar.data(), ag.data(), ab.data(), blur.data(), ior.data());
     if (rc == RTX_OK) rc = rtx_group_set_camera(grp, &cam);
     unsigned done = 0;

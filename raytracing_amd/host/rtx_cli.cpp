@@ -84,6 +84,12 @@ int main(int argc, char** argv)
     bool resume = args.cmdOptionExists("-R");
     if (resume && checkpoint.empty()) { printf("Error: -R needs -k <checkpoint file>.\n"); return -1; }
     bool binary = args.cmdOptionExists("-6");
+    int filter = -1;                                               // -F: how _sceneHit's candidates are found (results are identical)
+    if (args.cmdOptionExists("-F")) {
+        const std::string f = args.getCmdOption("-F");
+        filter = f == "valu" ? RTX_FILTER_VALU : f == "mfma" ? RTX_FILTER_MFMA : f == "grid" ? RTX_FILTER_GRID : f == "auto" ? RTX_FILTER_AUTO : -2;
+        if (filter == -2) { printf("Error: -F takes valu, mfma, grid or auto.\n"); return -1; }
+    }
 
     Scene* scene = randomScene(seed, variant);
     Camera camera(20, float(cols) / float(rows), 0.1f, 10.0f, vector3(13, 2, 3), vector3(0, 1, 0), vector3(0, 0, 0));   // RayTracing.cpp:107-117
@@ -96,7 +102,7 @@ int main(int argc, char** argv)
     rtx_stats st{};
     struct PassCtx { std::string file; unsigned cols, rows, total; bool binary; } pc{ filename, cols, rows, (unsigned)aaSamples, binary };
     HipRenderOptions opt;
-    opt.seed = seed; opt.device = device; opt.n_devices = gpus; opt.stats = &st; opt.pass_spp = passSpp; opt.resume = resume;
+    opt.seed = seed; opt.device = device; opt.n_devices = gpus; opt.stats = &st; opt.pass_spp = passSpp; opt.resume = resume; opt.filter = filter;
     opt.checkpoint = checkpoint.empty() ? nullptr : checkpoint.c_str();
     opt.user = &pc;
     if (passSpp) opt.on_pass = [](const uint32_t* fb, unsigned done, void* user) -> bool {

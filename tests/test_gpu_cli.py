@@ -76,3 +76,18 @@ def test_render_dist_matches_rtx_cli_and_resumes(tmp_path):
     assert r.returncode == 0 and "starting over" in r.stdout and r.stdout.count("pass done") == 1, r.stdout + r.stderr
     r = subprocess.run([cli] + common + ["-a", "2", "-f", str(a)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_cli_filter_flag(tmp_path):
+    """-F valu|mfma|grid|auto: the same image file whichever way the candidates are found; an unknown name is refused."""
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    base = [cli, "-w", "64", "-h", "40", "-m", "8", "-s", "5", "-a", "3", "-6", "-n", "scaled"]
+    images = []
+    for f in ("valu", "mfma", "grid", "auto"):
+        out = tmp_path / (f + ".ppm")
+        r = subprocess.run(base + ["-F", f, "-f", str(out)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        images.append(open(out, "rb").read())
+    assert all(img == images[0] for img in images[1:])
+    r = subprocess.run(base + ["-F", "bvh", "-f", str(tmp_path / "x.ppm")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "-F takes" in r.stdout

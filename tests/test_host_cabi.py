@@ -207,3 +207,60 @@ def test_library_imports_rccl():
     out = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "raytracing_amd", "librtx.so")], text=True)
     for sym in ("ncclAllReduce", "ncclCommInitAll", "ncclGroupStart", "ncclGroupEnd"):
         assert (" U " + sym) in out, sym
+
+
+def _grid_cells_of(g, lo, hi):
+    """Cell index ranges (inclusive, clamped) that the box [lo, hi] touches."""
+    a = np.clip(np.floor((lo - g["gmin"]) / g["h"]), 0, g["dim"] - 1).astype(np.int64)
+    b = np.clip(np.floor((hi - g["gmin"]) / g["h"]), 0, g["dim"] - 1).astype(np.int64)
+    return a, b
+
+
+@pytest.mark.parametrize("density", [12, 35, 400])
+def test_grid_construction_guarantees(ra, golden_scenes, density):
+    """rtx_build_grid (the host half of RTX_FILTER_GRID): every sphere is either on the big list or registered in every cell
+    that its padded bounding box touches; cell lists ascend; the box of the grid contains every binned sphere; the ground
+    sphere is big; CSR offsets are consistent."""
+    for name in ("book1", "scaled"):
+        table = golden_scenes[name]
+        g = ra.build_grid(table, density)
+        dim, start, items, big = g["dim"], g["cell_start"], g["items"], set(g["big"].tolist())
+        assert start[0] == 0 and start[-1] == len(items) and (np.diff(start.astype(np.int64)) >= 0).all()
+        assert (dim >= 1).all() and (dim <= 256).all() and g["pad"] > 0
+        assert 0 in big and len(big) < 8                      # the ground sphere (index 0, radius 1000) and at most the three large ones
+        cells = {}
+        for c in range(len(start) - 1):
+            lst = items[start[c]:start[c + 1]]
+            assert (np.diff(lst.astype(np.int64)) > 0).all()          # ascending, no duplicates
+            cells[c] = set(lst.tolist())
+        for i, row in enumerate(table):
+            if i in big:
+                assert all(i not in s for s in cells.values())
+                continue
+            ctr, r = row[0:3].astype(np.float64), abs(float(row[3]))
+            assert ((ctr - r) >= g["gmin"]).all() and ((ctr + r) <= g["gmin"] + g["h"].astype(np.float64) * dim * (1 + 1e-6)).all()
+            a, b = _grid_cells_of(g, ctr - r - 0.999 * g["pad"], ctr + r + 0.999 * g["pad"])
+            for z in range(a[2], b[2] + 1):
+                for y in range(a[1], b[1] + 1):
+                    for x in range(a[0], b[0] + 1):
+                        assert i in cells[(z * dim[1] + y) * dim[0] + x], (name, i, x, y, z)
+        binned = len(table) - len(big)
+        assert len(items) >= binned
+        mean = binned / float(np.prod(dim))
+        assert mean < 4.0 * density / 100.0 + 1.0              # resolution follows the density knob (thin axes collapse, hence the slack)
+
+
+def test_grid_degenerate_inputs(ra):
+    """No spheres, non-finite spheres and spheres that all exceed the grid give no cells and everything on the big list."""
+    empty = ra.build_grid(np.zeros((0, 10), dtype=np.float32))
+    assert empty["dim"].tolist() == [0, 0, 0] and len(empty["items"]) == 0 and len(empty["big"]) == 0
+    t = np.zeros((3, 10), dtype=np.float32)
+    t[:, 3] = 1.0
+    t[0, 0] = np.nan
+    t[1, 1] = np.inf
+    g = ra.build_grid(t)
+    assert set(g["big"].tolist()) >= {0, 1}
+    assert all(i in set(g["big"].tolist()) or i in set(g["items"].tolist()) for i in range(3))
+    one = ra.build_grid(np.array([[1, 2, 3, 0.5, 1, 0, 0, 0, 0, 1]], dtype=np.float32))
+    assert (len(one["big"]) == 1) != (0 in set(one["items"].tolist()))
+    assert ra.lib().rtx_build_grid(0, None, None, None, None, 0, None, None, 0, None, 0, None, 0) != 0     # NULL info / density 0
