@@ -251,18 +251,25 @@ int rtx_plan_chunks(uint32_t spp_count, uint64_t n_pixels, uint64_t lanes, uint3
 
 /* The uniform grid of RTX_FILTER_GRID as a pure function (no GPU, no counterpart in the reference; for tests and inspection):
  * what rtx_upload_scene builds for these spheres at `density_pct` spheres per cell x 100.  info is always filled; the arrays
- * are filled when non-NULL and large enough (cell_start: dim[0]*dim[1]*dim[2] + 1 entries, items: n_items, big: n_big), else
- * RTX_ERR_ARG.  Cell (x, y, z) = index (z*dim[1] + y)*dim[0] + x holds the spheres items[cell_start[c] .. cell_start[c+1]). */
+ * are filled when non-NULL and large enough (cell_start: ncells + 1 entries with ncells = dim[0]*dim[1]*dim[2], items: n_items,
+ * big: n_big, tier_end: 3 * ncells), else RTX_ERR_ARG.  Cell (x, y, z) = index c = (z*dim[1] + y)*dim[0] + x holds the spheres
+ * items[cell_start[c] .. cell_start[c+1]) in three parts that end at tier_end[3c], tier_end[3c+1], tier_end[3c+2]: tier k
+ * registers a sphere wherever its bounding box grown by pad + blur(r, tier_l[k]) reaches (the reference's fp32 sphere test
+ * accepts rays that pass a sphere at up to blur(r, L) = sqrt(r^2 + 2^-19 (L^2 + r^2)) - r beyond its surface when the ray's
+ * origin is L away); a ray reads the parts 0..k of its cells when it cannot get farther than tier_s[k] (k = 0, 1) from its
+ * origin inside the grid; tier_s[2] = tier_l[2] is the distance beyond which the table is scanned instead. */
 typedef struct rtx_grid_info {
     float    gmin[3], inv_h[3], h[3];
     uint32_t dim[3];
     float    pad;
     uint32_t n_big;
     uint64_t n_items;
+    float    tier_s[3];
+    double   tier_l[3], tier_grow[3];
 } rtx_grid_info;
 int rtx_build_grid(uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius, uint32_t density_pct,
                    rtx_grid_info* info, uint32_t* cell_start, uint64_t cell_start_cap, uint32_t* items, uint64_t items_cap,
-                   uint32_t* big, uint64_t big_cap);
+                   uint32_t* big, uint64_t big_cap, uint32_t* tier_end, uint64_t tier_end_cap);
 
 /* RayTracing.cpp:152-165: "P3\n<cols> <rows>\n255\n" then "r g b\n" per pixel. */
 int rtx_write_ppm(const char* path, uint32_t cols, uint32_t rows, const uint32_t* framebuffer_host);

@@ -44,7 +44,8 @@ class Stats(C.Structure):
 class GridInfo(C.Structure):
     """rtx_grid_info: the uniform grid of FILTER_GRID (rtx_build_grid)."""
     _fields_ = [("gmin", C.c_float * 3), ("inv_h", C.c_float * 3), ("h", C.c_float * 3), ("dim", C.c_uint32 * 3),
-                ("pad", C.c_float), ("n_big", C.c_uint32), ("n_items", C.c_uint64)]
+                ("pad", C.c_float), ("n_big", C.c_uint32), ("n_items", C.c_uint64), ("tier_s", C.c_float * 3),
+                ("tier_l", C.c_double * 3), ("tier_grow", C.c_double * 3)]
 
 
 _lib = None
@@ -108,7 +109,7 @@ def lib():
     L.rtx_scene_capacity.argtypes = [C.c_int]
     L.rtx_random_scene.argtypes = [u64, C.c_int, f32, f32, up, fp, fp, fp, fp, up, fp, fp, fp, fp, fp]
     L.rtx_plan_chunks.argtypes = [u32, u64, u64, u32, u32, u32, u64, up, u32, up]
-    L.rtx_build_grid.argtypes = [u32, fp, fp, fp, fp, u32, P(GridInfo), up, u64, up, u64, up, u64]
+    L.rtx_build_grid.argtypes = [u32, fp, fp, fp, fp, u32, P(GridInfo), up, u64, up, u64, up, u64, up, u64]
     L.rtx_write_ppm.argtypes = [C.c_char_p, u32, u32, up]
     L.rtx_write_ppm_p6.argtypes = [C.c_char_p, u32, u32, up]
     L.rtx_save_accum.argtypes = [C.c_void_p, C.c_char_p, u32, u64, u32, u32]
@@ -222,20 +223,23 @@ def plan_chunks(spp_count, n_pixels, lanes, items_per_lane=256, max_chunks=63, t
 
 def build_grid(table, density_pct=35):
     """The uniform grid that upload_scene builds for FILTER_GRID (rtx_build_grid; host arithmetic only): a dict with gmin, h,
-    inv_h, dim, pad and the arrays cell_start, items, big."""
+    inv_h, dim, pad, the arrays cell_start, items, big and the registration tiers (tier_end per cell, tier_s, tier_l, tier_grow)."""
     t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1, 10)
     cols = [np.ascontiguousarray(t[:, k]) for k in range(4)]
     info = GridInfo()
     null = C.POINTER(C.c_uint32)()
-    _check(lib().rtx_build_grid(len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), density_pct, C.byref(info), null, 0, null, 0, null, 0))
+    _check(lib().rtx_build_grid(len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), density_pct, C.byref(info), null, 0, null, 0, null, 0, null, 0))
     ncell = int(info.dim[0]) * int(info.dim[1]) * int(info.dim[2])
     cell_start = np.zeros(ncell + 1, dtype=np.uint32)
     items = np.zeros(max(1, info.n_items), dtype=np.uint32)
     big = np.zeros(max(1, info.n_big), dtype=np.uint32)
+    tier_end = np.zeros(max(1, 3 * ncell), dtype=np.uint32)
     _check(lib().rtx_build_grid(len(t), _fp(cols[0]), _fp(cols[1]), _fp(cols[2]), _fp(cols[3]), density_pct, C.byref(info),
-                                _up(cell_start), cell_start.size, _up(items), items.size, _up(big), big.size))
+                                _up(cell_start), cell_start.size, _up(items), items.size, _up(big), big.size, _up(tier_end), tier_end.size))
     return {"gmin": np.array(info.gmin[:], dtype=np.float32), "h": np.array(info.h[:], dtype=np.float32), "inv_h": np.array(info.inv_h[:], dtype=np.float32),
-            "dim": np.array(info.dim[:], dtype=np.int64), "pad": float(info.pad), "cell_start": cell_start, "items": items[:info.n_items], "big": big[:info.n_big]}
+            "dim": np.array(info.dim[:], dtype=np.int64), "pad": float(info.pad), "cell_start": cell_start, "items": items[:info.n_items], "big": big[:info.n_big],
+            "tier_end": tier_end[:3 * ncell].reshape(-1, 3), "tier_s": np.array(info.tier_s[:], dtype=np.float32),
+            "tier_l": np.array(info.tier_l[:]), "tier_grow": np.array(info.tier_grow[:])}
 
 
 def write_ppm(path, cols, rows, framebuffer, binary=False):

@@ -83,7 +83,7 @@ struct rtx_ctx {
     float4*  exact = nullptr;
     uint4*   mat = nullptr;
     GridDesc  grid{};                // RTX_FILTER_GRID: built at upload (rtx_host.cpp, build_grid)
-    uint2* grid_range = nullptr; float4* grid_geom = nullptr; uint32_t* grid_items = nullptr; uint32_t* grid_big = nullptr;
+    uint4* grid_cells = nullptr; float4* grid_geom = nullptr; uint32_t* grid_items = nullptr; uint32_t* grid_big = nullptr;
     bool     have_scene = false, have_camera = false;
     rtx_camera cam{};
     // frame
@@ -151,7 +151,7 @@ extern "C" int rtx_destroy(rtx_ctx* c)
     if (!c) return RTX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->grid_range, c->grid_geom, c->grid_items, c->grid_big, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats };
+    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->grid_cells, c->grid_geom, c->grid_items, c->grid_big, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats };
     for (void* b : bufs) if (b) (void)hipFree(b);
     hipEvent_t evs[] = { c->ev_first, c->ev_last, c->ev_t0, c->ev_t1 };
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -283,19 +283,19 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     {
         GridHost G;
         build_grid(n, cx, cy, cz, radius, c->tune.grid_density_pct / 100.0, &G);
-        void* old[] = { c->grid_range, c->grid_geom, c->grid_items, c->grid_big };
+        void* old[] = { c->grid_cells, c->grid_geom, c->grid_items, c->grid_big };
         for (void* b : old) if (b) (void)hipFree(b);
-        c->grid_range = nullptr; c->grid_geom = nullptr; c->grid_items = c->grid_big = nullptr;
-        // device form: (begin, end) per cell in one 8-byte word, and the geometry copied next to every registration
-        std::vector<uint2>  range(G.cell_start.empty() ? 0 : G.cell_start.size() - 1);
+        c->grid_cells = nullptr; c->grid_geom = nullptr; c->grid_items = c->grid_big = nullptr;
+        // device form: (begin, end of tier 0, 1, 2) per cell in one 16-byte word, and the geometry copied next to every registration
+        std::vector<uint4>  range(G.cell_start.empty() ? 0 : G.cell_start.size() - 1);
         std::vector<float4> geom(G.items.size());
-        for (size_t k = 0; k < range.size(); ++k) range[k] = make_uint2(G.cell_start[k], G.cell_start[k + 1]);
+        for (size_t k = 0; k < range.size(); ++k) range[k] = make_uint4(G.cell_start[k], G.tier_end[3 * k], G.tier_end[3 * k + 1], G.tier_end[3 * k + 2]);
         for (size_t k = 0; k < geom.size(); ++k) geom[k] = exact[G.items[k]];
-        HIP_TRY(hipMalloc(&c->grid_range, std::max<size_t>(range.size(), 1) * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&c->grid_cells, std::max<size_t>(range.size(), 1) * sizeof(uint4)));
         HIP_TRY(hipMalloc(&c->grid_geom, std::max<size_t>(geom.size(), 1) * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->grid_items, std::max<size_t>(G.items.size(), 1) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->grid_big, std::max<size_t>(G.big.size(), 1) * sizeof(uint32_t)));
-        if (!range.empty()) HIP_TRY(hipMemcpy(c->grid_range, range.data(), range.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        if (!range.empty()) HIP_TRY(hipMemcpy(c->grid_cells, range.data(), range.size() * sizeof(uint4), hipMemcpyHostToDevice));
         if (!geom.empty()) HIP_TRY(hipMemcpy(c->grid_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
         if (!G.items.empty()) HIP_TRY(hipMemcpy(c->grid_items, G.items.data(), G.items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!G.big.empty()) HIP_TRY(hipMemcpy(c->grid_big, G.big.data(), G.big.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -479,7 +479,7 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
     if (c->tune.wave_batch) wave_batch = (uint32_t)c->tune.wave_batch;
     if ((uint64_t)R.n_items + (uint64_t)R.lp.max_grid * (R.lp.block / 64u) * 2u * wave_batch >= (1ull << 32)) return fail(RTX_ERR_ARG, "%s: work counter would overflow; raise chunk_spp", who);
 
-    P.grid = c->grid; P.grid_range = c->grid_range; P.grid_geom = c->grid_geom; P.grid_items = c->grid_items; P.grid_big = c->grid_big;
+    P.grid = c->grid; P.grid_cells = c->grid_cells; P.grid_geom = c->grid_geom; P.grid_items = c->grid_items; P.grid_big = c->grid_big;
     P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.mfma_scale = c->mfma_scale; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
     P.cols = cols; P.rows = rows; P.npix = R.npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = R.nchunks;
     P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = R.n_items; P.wave_batch = wave_batch;

@@ -54,8 +54,8 @@ struct TraceParams {
     const float4* hot_mfma; // (n_pad_mfma/32 + 1) tiles x 2 MFMAs x 64 lanes x 16 B: f16 A operands (ten monomials per sphere) of the MFMA filter
     uint32_t      n_pad_mfma;
     float         mfma_scale; // power of two applied to the sphere side of the MFMA filter (f16 range)
-    GridDesc      grid;       // RTX_FILTER_GRID: uniform grid over the table (rtx_plan.h); cell c holds the entries [grid_range[c].x, grid_range[c].y) of grid_geom (centre, radius: a copy, so that a test is one load behind the cell's) / grid_items (sphere index)
-    const uint2*    grid_range;
+    GridDesc      grid;       // RTX_FILTER_GRID: uniform grid over the table (rtx_plan.h); cell c holds the entries [grid_cells[c].x, grid_cells[c].w) of grid_geom (centre, radius: a copy, so that a test is one load behind the cell's) / grid_items (sphere index); .y, .z, .w end the registration tiers 0, 1, 2
+    const uint4*    grid_cells;
     const float4*   grid_geom;
     const uint32_t* grid_items;
     const uint32_t* grid_big;  // grid.n_big spheres tested for every ray

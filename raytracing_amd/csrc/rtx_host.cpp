@@ -89,32 +89,60 @@ uint32_t rtx::plan_chunks(uint32_t spp_count, uint64_t npix, uint64_t lanes, uin
 // Uniform grid for RTX_FILTER_GRID (an acceleration structure over the SoA table; no counterpart in the
 // reference, whose _sceneHit is the linear loop of raytracer.cpp:285-304).  The grid only decides WHICH spheres a ray is
 // tested against; the test itself stays the exact sphere.cpp:68-102 arithmetic and the winner the minimum of (t, index), so
-// results cannot change as long as no sphere that the ray can hit is skipped.  That is what the construction guarantees:
-//   * a sphere is registered in every cell that its bounding box, grown by `pad`, overlaps; `pad` (2^-12 of the largest
-//     coordinate or extent) is some hundred times the error of the traversal's fp32 arithmetic, so a hit point that the
-//     traversal places in the neighbouring cell is still found there;
-//   * spheres whose box would cover more than an eighth of the cells (at least 8, at most 512: the ground sphere) are not binned
-//     but tested for every ray; the grid is then laid out again over the rest;
-//   * the traversal (trace_kernel.hip) visits the cells a ray crosses in order and stops early only when the closest hit so
-//     far lies more than `pad` before the current cell's exit.
+// results cannot change as long as no sphere that the REFERENCE'S fp32 test accepts is skipped.  That test is blurred: with
+// u = 2^-24, L = |o - c| and the uncontracted evaluation order of sphere.cpp:72-78,
+//     |disc_fp32 - a (r^2 - dist^2)|  <=  20 u a (L^2 + r^2)        (dist: distance of the centre from the ray's line)
+// (oc: u per component; b = oc.d: 4 u L |d|; b^2: 9 u a L^2; oc.oc: 5 u L^2; c: 6 u L^2 + 2 u r^2; a c: u a (10 L^2 + 6 r^2); the
+// last subtraction: u a (L^2 + r^2)), so a sphere can be "hit" by rays that pass it at up to
+//     blur(r, L) = sqrt(r^2 + 2^-19 (L^2 + r^2)) - r                (2^-19 = 32 u: the bound with a margin)
+// beyond its surface: 0.0007 for r = 0.2 at L = 15, 0.03 at L = 100, 0.9 at L = 800 -- far away the reference renders noise,
+// and the grid has to reproduce it.  The accepted root t then lies on the part of the ray inside the ball of radius
+// r + blur(r, L), hence inside the sphere's bounding box grown by that much.  Construction:
+//   * three registration TIERS for origin-to-sphere distances up to L_k = L/4, L/2, L with L = two diagonals of the binned
+//     spheres' bounds (less in large scenes, see below):
+//     in tier k a sphere is registered in every cell that its bounding box grown by pad + blur(r, L_k) overlaps.  A cell's list
+//     is stored tier by tier (tier 0, then what tier 1 adds, then what tier 2 adds).  A ray reads the lists 0..k of its cells
+//     when the farthest point its walk can reach -- the box's exit or a hit already found on the big list -- is at most
+//     tier_s[k] = L_k - (cell diagonal + largest binned radius + pad + largest blur of tier k) from its origin.  An origin from
+//     which a binned sphere can be farther than L_2 (distance to the box + the box's diagonal > L_2: far-away cameras) is beyond
+//     the registrations: such a ray is clipped against the box grown by the blur of that distance and, if it enters, scans the
+//     whole table;
+//   * `pad` = 2^-12 of the largest coordinate or extent covers the walk's own arithmetic: the slab clip and the accumulated
+//     cell-exit parameters are off by at most 256 roundings of a parameter whose distance equivalent is <= 2 diagonals
+//     (far_l), i.e. < 2^-14 of the extent, and b / a by 4 u L; a hit point that the walk places in the neighbouring cell is
+//     still found there, and the walk stops early only when the closest hit so far lies more than 2 pad before the exit of the
+//     cell just finished (an untested sphere's registered stretch of the ray starts after that exit, and its root lies on
+//     that stretch);
+//   * the grid box is the binned spheres' bounds grown by the largest registration radius, so that every registered stretch
+//     of a ray lies inside the box; an axis that is one cell thick stays one cell thick;
+//   * spheres whose tier-0 box would cover more than an eighth of the cells (at least 8, at most 512: the ground sphere) are
+//     not binned but tested for every ray; the grid is then laid out again over the rest.
 // Resolution: `per_cell` spheres per cell (tuning key "grid_density_pct", default 0.35: measured flat between 0.125 and 0.5 on
 // the book-1 and 20 164-sphere scenes, profiles/r02c_grid_filter.txt), cells as cubic as the extent allows, at most 256 cells per axis.
+double rtx::grid_blur(double r, double l)
+{
+    r = std::fabs(r);
+    return std::sqrt(r * r + std::ldexp(l * l + r * r, -19)) - r;
+}
+
 void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius, double per_cell, GridHost* out)
 {
     GridHost& G = *out;
     G = GridHost();
     memset(&G.desc, 0, sizeof(G.desc));
+    for (int t = 0; t < 3; ++t) { G.tier_l[t] = 0.0; G.tier_grow[t] = 0.0; }
     std::vector<uint32_t> cand;
     std::vector<uint8_t>  is_big(n, 0);
     for (int round = 0; round < 8; ++round) {
         // bounds of the spheres that are (still) meant for the grid
-        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 }, r_max = 0.0;
         cand.clear();
         for (uint32_t i = 0; i < n; ++i) {
             const double c[3] = { cx[i], cy[i], cz[i] }, r = std::fabs((double)radius[i]);
             if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(r))) { is_big[i] = 1; continue; }   // the exact test decides
             if (is_big[i]) continue;
             cand.push_back(i);
+            r_max = std::max(r_max, r);
             for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k] - r); hi[k] = std::max(hi[k], c[k] + r); }
         }
         if (cand.empty()) break;
@@ -122,6 +150,7 @@ void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* 
         for (int k = 0; k < 3; ++k) { ext[k] = hi[k] - lo[k]; big_coord = std::max(big_coord, std::max(std::max(std::fabs(lo[k]), std::fabs(hi[k])), ext[k])); }
         const double pad = std::max(big_coord * std::ldexp(1.0, -12), 1e-30);
         for (int k = 0; k < 3; ++k) { lo[k] -= 2.0 * pad; hi[k] += 2.0 * pad; ext[k] = hi[k] - lo[k]; }
+        const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
         // cell size: (volume * per_cell / count)^(1/3), but a thin extent is one cell thick and then no longer counts as a dimension
         double h = std::cbrt(ext[0] * ext[1] * ext[2] * per_cell / (double)cand.size());
         for (int pass = 0; pass < 3; ++pass) {
@@ -131,18 +160,34 @@ void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* 
             if (dims == 0) break;
             h = std::pow(vol, 1.0 / dims);
         }
+        // Tier limits: the outermost reaches two diagonals, less where the blur of the smallest sphere would exceed a quarter of a
+        // cell by then (large scenes: the box and every far list grow with it), but never less than 1.1 diagonals, so that a ray
+        // that starts inside the box is always served; the inner tiers halve it.
+        double r_min = r_max;
+        for (uint32_t i : cand) r_min = std::min(r_min, std::fabs((double)radius[i]));
+        double l_out = 2.0 * diag;
+        if (grid_blur(r_min, l_out) > 0.25 * h) {
+            double lo_l = 0.0, hi_l = l_out;                // blur is monotonic in l: bisect
+            for (int it = 0; it < 60; ++it) { const double mid = 0.5 * (lo_l + hi_l); (grid_blur(r_min, mid) > 0.25 * h ? hi_l : lo_l) = mid; }
+            l_out = std::max(1.1 * diag, lo_l);
+        }
+        const double tier_l[3] = { 0.25 * l_out, 0.5 * l_out, l_out };
+        double grow[3] = { pad, pad, pad };
+        for (uint32_t i : cand)
+            for (int t = 0; t < 3; ++t) grow[t] = std::max(grow[t], pad + grid_blur(radius[i], tier_l[t]));
         uint32_t dim[3];
         double   hk[3];
         for (int k = 0; k < 3; ++k) {
             dim[k] = (uint32_t)std::min(256.0, std::max(1.0, std::floor(ext[k] / std::max(h, 1e-300))));
-            hk[k]  = ext[k] / dim[k];
+            lo[k] -= grow[2]; hi[k] += grow[2];             // every registered stretch of a ray lies inside the box
+            hk[k]  = (hi[k] - lo[k]) / dim[k];
         }
         // which spheres are too large for this grid?
         const uint64_t all_cells = (uint64_t)dim[0] * dim[1] * dim[2];
         const uint64_t kBigCells = std::max<uint64_t>(8, std::min<uint64_t>(512, all_cells / 8));
         bool changed = false;
         for (uint32_t i : cand) {
-            const double r = std::fabs((double)radius[i]) + pad;
+            const double r = std::fabs((double)radius[i]) + pad + grid_blur(radius[i], tier_l[0]);
             uint64_t cells = 1;
             for (int k = 0; k < 3; ++k) cells *= (uint64_t)std::min<double>(dim[k], std::floor(2.0 * r / hk[k]) + 2.0);
             if (cells > kBigCells) { is_big[i] = 1; changed = true; }
@@ -151,31 +196,49 @@ void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* 
         GridDesc& D = G.desc;
         for (int k = 0; k < 3; ++k) { D.gmin[k] = (float)lo[k]; D.h[k] = (float)hk[k]; D.inv_h[k] = (float)(1.0 / hk[k]); D.dim[k] = dim[k]; }
         D.pad = (float)pad;
+        const double cell_diag = std::sqrt(hk[0] * hk[0] + hk[1] * hk[1] + hk[2] * hk[2]);
+        for (int t = 0; t < 3; ++t) { G.tier_l[t] = tier_l[t]; G.tier_grow[t] = grow[t]; }
+        // rounded down a little: the kernel compares fp32 distances with these
+        for (int t = 0; t < 2; ++t) D.tier_s[t] = (float)std::max(0.0, (tier_l[t] - (cell_diag + r_max + grow[t])) * (1.0 - 1e-5));
+        D.far_l    = (float)(tier_l[2] * (1.0 - 1e-5));
+        D.box_diag = (float)(std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2])) * (1.0 + 1e-5));
+        D.r_min    = (float)(r_min * (1.0 - 1e-5));
         const size_t ncells = (size_t)dim[0] * dim[1] * dim[2];
-        G.cell_start.assign(ncells + 1, 0u);
-        auto range = [&](uint32_t i, int k, uint32_t* a, uint32_t* b) {
-            const double c = k == 0 ? cx[i] : (k == 1 ? cy[i] : cz[i]), r = std::fabs((double)radius[i]) + pad;
+        auto range = [&](uint32_t i, int k, int t, uint32_t* a, uint32_t* b) {
+            const double c = k == 0 ? cx[i] : (k == 1 ? cy[i] : cz[i]), r = std::fabs((double)radius[i]) + pad + grid_blur(radius[i], tier_l[t]);
             const double ga = (c - r - lo[k]) / hk[k], gb = (c + r - lo[k]) / hk[k];
             *a = (uint32_t)std::min<double>(dim[k] - 1, std::max(0.0, std::floor(ga)));
             *b = (uint32_t)std::min<double>(dim[k] - 1, std::max(0.0, std::floor(gb)));
         };
+        std::vector<uint32_t> count(ncells * 3, 0u), cursor;
         for (int fill = 0; fill < 2; ++fill) {
-            std::vector<uint32_t> cursor;
             if (fill) {
+                G.cell_start.assign(ncells + 1, 0u);
+                G.tier_end.assign(ncells * 3, 0u);
+                cursor.assign(ncells * 3, 0u);
                 uint32_t run = 0;
-                for (size_t c = 0; c < ncells; ++c) { const uint32_t cnt = G.cell_start[c]; G.cell_start[c] = run; run += cnt; }
+                for (size_t c = 0; c < ncells; ++c) {
+                    G.cell_start[c] = run;
+                    for (int t = 0; t < 3; ++t) { cursor[c * 3 + t] = run; run += count[c * 3 + t]; G.tier_end[c * 3 + t] = run; }
+                }
                 G.cell_start[ncells] = run;
                 G.items.assign(run, 0u);
-                cursor.assign(G.cell_start.begin(), G.cell_start.end() - 1);
             }
             for (uint32_t i : cand) {
-                uint32_t a[3], b[3];
-                for (int k = 0; k < 3; ++k) range(i, k, &a[k], &b[k]);
-                for (uint32_t z = a[2]; z <= b[2]; ++z)
-                    for (uint32_t y = a[1]; y <= b[1]; ++y)
-                        for (uint32_t x = a[0]; x <= b[0]; ++x) {
+                uint32_t a[3][3], b[3][3];
+                for (int t = 0; t < 3; ++t) for (int k = 0; k < 3; ++k) range(i, k, t, &a[t][k], &b[t][k]);
+                for (uint32_t z = a[2][2]; z <= b[2][2]; ++z)
+                    for (uint32_t y = a[2][1]; y <= b[2][1]; ++y)
+                        for (uint32_t x = a[2][0]; x <= b[2][0]; ++x) {
+                            const uint32_t p[3] = { x, y, z };
+                            int tier = 2;
+                            for (int t = 1; t >= 0; --t) {
+                                bool in = true;
+                                for (int k = 0; k < 3; ++k) in = in && p[k] >= a[t][k] && p[k] <= b[t][k];
+                                if (in) tier = t;
+                            }
                             const size_t c = ((size_t)z * dim[1] + y) * dim[0] + x;
-                            if (fill) G.items[cursor[c]++] = i; else G.cell_start[c]++;
+                            if (fill) G.items[cursor[c * 3 + tier]++] = i; else count[c * 3 + tier]++;
                         }
             }
         }
@@ -187,16 +250,18 @@ void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* 
 
 extern "C" int rtx_build_grid(uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius, uint32_t density_pct,
                               rtx_grid_info* info, uint32_t* cell_start, uint64_t cell_start_cap, uint32_t* items, uint64_t items_cap,
-                              uint32_t* big, uint64_t big_cap)
+                              uint32_t* big, uint64_t big_cap, uint32_t* tier_end, uint64_t tier_end_cap)
 {
     if (!info || (n && !(cx && cy && cz && radius)) || density_pct < 1 || density_pct > 6400) return RTX_ERR_ARG;
     rtx::GridHost G;
     rtx::build_grid(n, cx, cy, cz, radius, density_pct / 100.0, &G);
     for (int k = 0; k < 3; ++k) { info->gmin[k] = G.desc.gmin[k]; info->inv_h[k] = G.desc.inv_h[k]; info->h[k] = G.desc.h[k]; info->dim[k] = G.desc.dim[k]; }
     info->pad = G.desc.pad; info->n_big = G.desc.n_big; info->n_items = G.items.size();
+    for (int t = 0; t < 3; ++t) { info->tier_s[t] = t < 2 ? G.desc.tier_s[t] : G.desc.far_l; info->tier_l[t] = G.tier_l[t]; info->tier_grow[t] = G.tier_grow[t]; }
     if (cell_start) { if (cell_start_cap < G.cell_start.size()) return RTX_ERR_ARG; std::copy(G.cell_start.begin(), G.cell_start.end(), cell_start); }
     if (items)      { if (items_cap < G.items.size()) return RTX_ERR_ARG; std::copy(G.items.begin(), G.items.end(), items); }
     if (big)        { if (big_cap < G.big.size()) return RTX_ERR_ARG; std::copy(G.big.begin(), G.big.end(), big); }
+    if (tier_end)   { if (tier_end_cap < G.tier_end.size()) return RTX_ERR_ARG; std::copy(G.tier_end.begin(), G.tier_end.end(), tier_end); }
     return RTX_OK;
 }
 

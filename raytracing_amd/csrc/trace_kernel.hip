@@ -27,6 +27,7 @@
 // square root, so a path is bit-identical to the CPU restatement of the reference.  Only the candidate filter uses
 // FMAs, MFMAs and a reciprocal square root; it is conservative (never drops a sphere the exact test would accept),
 // so it cannot change a result -- only how many exact tests run.
+#include <cstddef>
 #include "rtx_device.h"
 
 #include <type_traits>
@@ -186,8 +187,12 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     const size_t   stack_stride = (size_t)gridDim.x * blockDim.x;
     float4* const  att_stack    = P.att_stack + ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
 
-    const V3 cam_o = ld3(P.cam.origin), cam_lc = ld3(P.cam.left_corner), cam_h = ld3(P.cam.horizontal), cam_v = ld3(P.cam.vertical);
-    const V3 cam_uu = ld3(P.cam.u), cam_vv = ld3(P.cam.v);
+    // The camera's 19 constants: scalar registers for the whole kernel -- except in the grid variant, whose walk loop needs the
+    // scalar registers for itself (spilled ones come back as v_readlane, i.e. vector instructions, on every trip): there phase (B)
+    // reads them from the kernel-argument segment when it runs (the empty asm keeps the loads from being hoisted again).
+    V3 cam_o = ld3(P.cam.origin), cam_lc = ld3(P.cam.left_corner), cam_h = ld3(P.cam.horizontal), cam_v = ld3(P.cam.vertical);
+    V3 cam_uu = ld3(P.cam.u), cam_vv = ld3(P.cam.v);
+    float cam_lens = P.cam.lens_radius;
 
 #ifdef RTX_PHASE_TIMERS
     uint64_t ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -259,7 +264,16 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 t++;
             }
             if (go) {
-                float rx = P.cam.lens_radius * dkx, ry = P.cam.lens_radius * dky;
+                if constexpr (FILTER == kFilterGrid) {
+                    const char __attribute__((address_space(4)))* kargs = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(kargs));
+                    const rtx_camera __attribute__((address_space(4)))* cam = (const rtx_camera __attribute__((address_space(4)))*)(kargs + offsetof(TraceParams, cam));
+                    cam_o  = mk(cam->origin[0], cam->origin[1], cam->origin[2]);       cam_lc = mk(cam->left_corner[0], cam->left_corner[1], cam->left_corner[2]);
+                    cam_h  = mk(cam->horizontal[0], cam->horizontal[1], cam->horizontal[2]); cam_v  = mk(cam->vertical[0], cam->vertical[1], cam->vertical[2]);
+                    cam_uu = mk(cam->u[0], cam->u[1], cam->u[2]);                       cam_vv = mk(cam->v[0], cam->v[1], cam->v[2]);
+                    cam_lens = cam->lens_radius;
+                }
+                float rx = cam_lens * dkx, ry = cam_lens * dky;
                 V3    offset = add(scale(rx, cam_uu), scale(ry, cam_vv));
                 o = add(cam_o, offset);
                 d = sub(sub(add(add(cam_lc, scale(u, cam_h)), scale(1.0f - v, cam_v)), cam_o), offset);
@@ -314,17 +328,31 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 const uint32_t i = P.grid_big[k];
                 if (tracing) test(P.exact[i], [&] { return i; });
             }
+            bool scan_all = false;
             if (P.grid.dim[0] != 0u) {
                 const float inf = __builtin_inff();
                 const float slack_t = 2.0f * P.grid.pad * __builtin_amdgcn_rsqf(a);        // the registration slack as a ray parameter
-                // slab clip of the ray against the grid box; a zero component of d leaves that axis unbounded when the origin is inside
-                float    t_in = 0.0f, t_out = inf;
-                bool     walking = tracing;
+                // Is the origin within the registrations' reach?  If some binned sphere can be farther away than the outermost tier
+                // allows, the ray is clipped against the box grown by the blur of that distance and, if it enters, scans the table.
                 const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-                float    inv[3];
+                float s_near2 = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float lo = P.grid.gmin[k], hi = lo + (float)P.grid.dim[k] * P.grid.h[k];
+                    const float off = fmaxf(fmaxf(lo - oo[k], oo[k] - hi), 0.0f);
+                    s_near2 += off * off;
+                }
+                const float l_far = sqrtf(s_near2) * 1.000001f + P.grid.box_diag;
+                const bool  far   = !(l_far <= P.grid.far_l);                               // also NaN
+                const float rm    = P.grid.r_min;
+                const float extra = far ? P.grid.pad + (sqrtf(rm * rm + 1.9073486328125e-6f * (l_far * l_far + rm * rm)) * 1.000001f - rm) : 0.0f;
+                // slab clip of the ray against the grid box; a zero component of d leaves that axis unbounded when the origin is inside
+                float    t_in = 0.0f, t_out = inf;
+                bool     walking = tracing;
+                float    inv[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float lo = P.grid.gmin[k] - extra, hi = P.grid.gmin[k] + (float)P.grid.dim[k] * P.grid.h[k] + extra;
                     inv[k] = 1.0f / dd[k];
                     if (dd[k] != 0.0f) {
                         const float ta = (lo - oo[k]) * inv[k], tb = (hi - oo[k]) * inv[k];
@@ -335,6 +363,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
                 walking = walking && t_in <= t_out;
+                if (walking && far) { scan_all = true; walking = false; }
                 // Per axis: tn = parameter at which the ray leaves its current cell, dt = parameter per cell, the signed step of the
                 // linear cell index, and (10 bits each, packed in `rem`) how many cells are left before the ray leaves the grid.
                 // tn accumulates one rounding per step: at most 768 steps x 2^-24 of the largest parameter, a third of the
@@ -360,13 +389,19 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     }
                     cstride[k] = fwd ? (int)stride[k] : -(int)stride[k];
                 }
+                // Registration tier of this ray: the lists that are valid up to the farthest point the walk can reach, i.e. the
+                // box's exit or the hit already found on the big list (the ground), whichever is nearer -- one decision per ray
+                // instead of one per cell (the outermost tier is valid wherever the origin passed the test above).
+                const float s_max = fminf(t_out, closest + slack_t) * (sqrtf(a) * 1.000001f);     // as a distance, rounded up
+                const bool  tier1 = !(s_max <= P.grid.tier_s[0]), tier2 = !(s_max <= P.grid.tier_s[1]);   // NaN: the widest lists
                 uint32_t it = 0u, it_end = 0u;
                 bool     fresh_cell = true;
                 for (;;) {
                     if (!__ballot(walking)) break;
                     if (walking && fresh_cell) {
-                        const uint2 range = P.grid_range[cidx];
-                        it = range.x; it_end = range.y;
+                        const uint4 rec = P.grid_cells[cidx];
+                        it      = rec.x;
+                        it_end  = tier2 ? rec.w : (tier1 ? rec.z : rec.y);
                         fresh_cell = false;
                     }
                     if (walking && it < it_end) {
@@ -389,6 +424,13 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                             fresh_cell = true;
                         }
                     }
+                }
+            }
+            // rays that outran the grid's registrations (origins many scene diameters away): the reference's own loop
+            if (__ballot(scan_all)) {
+                for (uint32_t i = 0; i < P.n; ++i) {
+                    const float4 s = P.exact[i];
+                    if (scan_all) test(s, [&] { return i; });
                 }
             }
         } else {

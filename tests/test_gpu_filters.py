@@ -332,3 +332,41 @@ def test_auto_filter_picks_by_table_size(ra, golden_scenes):
             ctx.set_filter(4)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("case", ["across_the_field", "tiny_spheres", "from_far_away", "from_very_far_away"])
+def test_grid_filter_reproduces_the_far_field_noise(ra, case):
+    """Far from the ray's origin the reference's fp32 discriminant is noise of size 2^-19 (L^2 + r^2): a ray can "hit" a sphere
+    that it passes at a distance.  The grid registers spheres with that blur, tier by tier (rtx_host.cpp, build_grid), and rays
+    that outrun the outermost tier scan the whole table: with the full-scan validation on, no ray may disagree -- looking
+    across a wide field at grazing height, with spheres of radius 1e-3 and 0, and from cameras 3 and 300 field widths away."""
+    table = ra.random_scene(3, 40).copy()                      # 6 400 small spheres on a 80 x 80 field + the ground and the three large ones
+    cols, rows, spp = 160, 100, 2
+    pos, look, fov = (-38.0, 0.6, 0.5), (40.0, 0.2, 0.0), 30.0
+    if case == "tiny_spheres":
+        table[4::3, 3] = 1.0e-3
+        table[5::7, 3] = 0.0
+    elif case == "from_far_away":
+        pos, fov = (-250.0, 30.0, 20.0), 12.0
+    elif case == "from_very_far_away":
+        pos, fov = (-25000.0, 3000.0, 2000.0), 0.12
+    ctx = ra.Context(0)
+    try:
+        ctx.upload_scene(table)
+        ctx.set_camera(ra.Camera(fov, np.float32(cols) / np.float32(rows), 0.0, 10.0, pos, (0, 1, 0), look))
+        out = {}
+        for kind in (ra.FILTER_GRID, ra.FILTER_VALU):
+            ctx.set_filter(kind)
+            primary, st = ctx.render(cols, rows, 0, spp, 6, 11, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+            assert st["filter_misses"] == 0, (case, kind, st)
+            out[kind] = (primary, ctx.read_accum(), st)
+    finally:
+        ctx.close()
+    (p_g, a_g, s_g), (p_v, a_v, s_v) = out[ra.FILTER_GRID], out[ra.FILTER_VALU]
+    same = (bits(a_g) == bits(a_v)) | (np.isnan(a_g) & np.isnan(a_v))
+    assert (p_g == p_v).all() and same.all() and s_g["rays"] == s_v["rays"]
+    assert float((p_g > 3).mean()) > 0.02                      # small spheres are in view
+    if case in ("across_the_field", "tiny_spheres"):
+        assert s_g["candidates"] < 0.05 * s_g["sphere_tests"]  # served by the grid ...
+    if case == "from_very_far_away":
+        assert s_g["candidates"] > 0.3 * s_g["sphere_tests"]   # ... and here by the fallback scan (primary rays; the bounces use the grid)

@@ -216,38 +216,91 @@ def _grid_cells_of(g, lo, hi):
     return a, b
 
 
+def _blur(r, l):
+    """How far beyond its surface the reference's fp32 discriminant can still accept a ray, origin l away (rtx_host.cpp)."""
+    r = abs(float(r))
+    return np.sqrt(r * r + (l * l + r * r) * 2.0 ** -19) - r
+
+
 @pytest.mark.parametrize("density", [12, 35, 400])
 def test_grid_construction_guarantees(ra, golden_scenes, density):
-    """rtx_build_grid (the host half of RTX_FILTER_GRID): every sphere is either on the big list or registered in every cell
-    that its padded bounding box touches; cell lists ascend; the box of the grid contains every binned sphere; the ground
-    sphere is big; CSR offsets are consistent."""
+    """rtx_build_grid (the host half of RTX_FILTER_GRID): every sphere is either on the big list or, for each registration tier
+    k, in parts 0..k of every cell that its bounding box grown by pad + blur(r, tier_l[k]) touches; parts ascend; the grid box
+    contains every grown box; the ground sphere is big; offsets are consistent; the tiers' distance limits leave room for a
+    cell, a sphere and the growth."""
     for name in ("book1", "scaled"):
         table = golden_scenes[name]
         g = ra.build_grid(table, density)
-        dim, start, items, big = g["dim"], g["cell_start"], g["items"], set(g["big"].tolist())
+        dim, start, items, big, tend = g["dim"], g["cell_start"], g["items"], set(g["big"].tolist()), g["tier_end"].astype(np.int64)
+        ncell = int(np.prod(dim))
         assert start[0] == 0 and start[-1] == len(items) and (np.diff(start.astype(np.int64)) >= 0).all()
+        assert (tend[:, 0] >= start[:-1]).all() and (tend[:, 1] >= tend[:, 0]).all() and (tend[:, 2] >= tend[:, 1]).all() and (tend[:, 2] == start[1:]).all()
         assert (dim >= 1).all() and (dim <= 256).all() and g["pad"] > 0
         assert 0 in big and len(big) < 8                      # the ground sphere (index 0, radius 1000) and at most the three large ones
-        cells = {}
-        for c in range(len(start) - 1):
-            lst = items[start[c]:start[c + 1]]
-            assert (np.diff(lst.astype(np.int64)) > 0).all()          # ascending, no duplicates
-            cells[c] = set(lst.tolist())
+        ext = g["h"].astype(np.float64) * dim
+        diag = np.sqrt(((ext - 2 * g["tier_grow"][2]) ** 2).sum())
+        assert 1.1 * diag * (1 - 1e-3) <= g["tier_l"][2] <= 2 * diag * (1 + 1e-3)
+        assert np.allclose(g["tier_l"][:2], [0.25 * g["tier_l"][2], 0.5 * g["tier_l"][2]], rtol=1e-9)
+        cell_diag = np.sqrt((g["h"].astype(np.float64) ** 2).sum())
+        r_max = max(abs(float(r)) for i, r in enumerate(table[:, 3]) if i not in big)
+        for k in range(2):
+            assert g["tier_s"][k] <= g["tier_l"][k] - (cell_diag + r_max + g["tier_grow"][k]) + 1e-6 or g["tier_s"][k] == 0
+        assert g["tier_s"][2] <= g["tier_l"][2]                     # the limit for origins: beyond it the table is scanned
+        upto = []                                                   # per tier: cell -> set of spheres in parts 0..k
+        for k in range(3):
+            upto.append([set(items[start[c]:tend[c, k]].tolist()) for c in range(ncell)])
+        for c in range(ncell):
+            prev = start[c]
+            for k in range(3):
+                part = items[prev:tend[c, k]].astype(np.int64)
+                assert (np.diff(part) > 0).all()                  # ascending, no duplicates inside a part
+                prev = tend[c, k]
+            assert len(upto[2][c]) == tend[c, 2] - start[c]        # and none across the parts
         for i, row in enumerate(table):
             if i in big:
-                assert all(i not in s for s in cells.values())
+                assert all(i not in s for s in upto[2])
                 continue
             ctr, r = row[0:3].astype(np.float64), abs(float(row[3]))
-            assert ((ctr - r) >= g["gmin"]).all() and ((ctr + r) <= g["gmin"] + g["h"].astype(np.float64) * dim * (1 + 1e-6)).all()
-            a, b = _grid_cells_of(g, ctr - r - 0.999 * g["pad"], ctr + r + 0.999 * g["pad"])
-            for z in range(a[2], b[2] + 1):
-                for y in range(a[1], b[1] + 1):
-                    for x in range(a[0], b[0] + 1):
-                        assert i in cells[(z * dim[1] + y) * dim[0] + x], (name, i, x, y, z)
+            for k in range(3):
+                grow = 0.999 * g["pad"] + _blur(r, g["tier_l"][k])
+                assert grow <= g["tier_grow"][k] * (1 + 1e-9)
+                assert ((ctr - r - grow) >= g["gmin"] - 1e-4 * ext).all() and ((ctr + r + grow) <= g["gmin"] + ext * (1 + 1e-4)).all()
+                a, b = _grid_cells_of(g, ctr - r - grow, ctr + r + grow)
+                for z in range(a[2], b[2] + 1):
+                    for y in range(a[1], b[1] + 1):
+                        for x in range(a[0], b[0] + 1):
+                            assert i in upto[k][(z * dim[1] + y) * dim[0] + x], (name, i, k, x, y, z)
         binned = len(table) - len(big)
         assert len(items) >= binned
         mean = binned / float(np.prod(dim))
         assert mean < 4.0 * density / 100.0 + 1.0              # resolution follows the density knob (thin axes collapse, hence the slack)
+
+
+def test_grid_blur_bounds_the_fp32_discriminant():
+    """The bound behind the registration tiers: over random (o, d, c, r) the fp32 discriminant of sphere.cpp:72-78, evaluated
+    in the reference's operation order, differs from the real one by less than 20 u a (L^2 + r^2), u = 2^-24 -- so a ray
+    that it accepts passes within blur(r, L) of the sphere."""
+    rng = np.random.default_rng(5)
+    f32 = np.float32
+    worst = 0.0
+    for _ in range(20000):
+        scale = 10.0 ** rng.uniform(-2, 3)
+        o = (rng.normal(size=3) * scale).astype(f32)
+        c = (rng.normal(size=3) * scale).astype(f32)
+        r = f32(abs(rng.normal()) * scale * 10.0 ** rng.uniform(-3, 0))
+        d = rng.normal(size=3).astype(f32)
+        oc = o - c
+        bq = f32(f32(f32(oc[0] * d[0]) + f32(oc[1] * d[1])) + f32(oc[2] * d[2]))
+        ococ = f32(f32(f32(oc[0] * oc[0]) + f32(oc[1] * oc[1])) + f32(oc[2] * oc[2]))
+        a = f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2]))
+        cq = f32(ococ - f32(r * r))
+        disc = float(f32(f32(bq * bq) - f32(a * cq)))
+        od, dd, cd, rd = o.astype(np.float64), d.astype(np.float64), c.astype(np.float64), float(r)
+        ocd = od - cd
+        true = float((ocd @ dd) ** 2 - (dd @ dd) * (ocd @ ocd - rd * rd))
+        bound = 20.0 * 2.0 ** -24 * float(dd @ dd) * float(ocd @ ocd + rd * rd)
+        worst = max(worst, abs(disc - true) / bound)
+    assert worst < 1.0, worst
 
 
 def test_grid_degenerate_inputs(ra):
@@ -263,4 +316,4 @@ def test_grid_degenerate_inputs(ra):
     assert all(i in set(g["big"].tolist()) or i in set(g["items"].tolist()) for i in range(3))
     one = ra.build_grid(np.array([[1, 2, 3, 0.5, 1, 0, 0, 0, 0, 1]], dtype=np.float32))
     assert (len(one["big"]) == 1) != (0 in set(one["items"].tolist()))
-    assert ra.lib().rtx_build_grid(0, None, None, None, None, 0, None, None, 0, None, 0, None, 0) != 0     # NULL info / density 0
+    assert ra.lib().rtx_build_grid(0, None, None, None, None, 0, None, None, 0, None, 0, None, 0, None, 0) != 0     # NULL info / density 0
