@@ -76,6 +76,30 @@ def measured_traffic():
         return None
 
 
+def other_workloads(ra, device, book1):
+    """Side measurements outside the timed region (one GPU, the faster of two launches after a warm-up, trace-kernel time from HIP events):
+    BASELINE configuration 5 (20 164 spheres, 100 spp) with the linear list and with the uniform grid, and the
+    bench scene with the grid.  Informational: `value` above is configuration 2 with the linear list."""
+    out = {}
+    for name, table, spp in (("config5_20164_spheres_100spp", ra.random_scene(SEED, 71), 100), ("book1_100spp", book1, 100)):
+        for fname, kind in (("linear_list_mfma", ra.FILTER_MFMA), ("uniform_grid", ra.FILTER_GRID)):
+            ctx = ra.Context(device)
+            try:
+                ctx.set_filter(kind)
+                ctx.upload_scene(table)
+                ctx.set_camera(ra.book_camera(COLS, ROWS))
+                ctx.render(COLS, ROWS, 0, 2, DEPTH, SEED)
+                ms = 1e30
+                for _ in range(2):
+                    _, st = ctx.render(COLS, ROWS, 0, spp, DEPTH, SEED, want_stats=True)
+                    ms = min(ms, ctx.last_trace_ms())
+                out.setdefault(name, {})[fname] = {"msamples_per_s": round(st["samples"] / ms / 1e3, 1), "kernel_ms": round(ms, 3),
+                                                  "exact_tests_per_ray": round(st["candidates"] / max(1, st["rays"]), 2)}
+            finally:
+                ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +110,7 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--chunk-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (configuration 5, grid filter)")
     ap.add_argument("--strong", action="store_true", help="strong scaling (BASELINE's target): --spp is the IMAGE's sample count, split over the ranks by sample index")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and all-reduce even with one rank (rehearsal of the N > 1 path)")
     args = ap.parse_args()
@@ -203,6 +228,8 @@ def main():
                          "fp32_equivalent_tflops": round(achieved, 3),
                          "fp32_equivalent_note": "SURVEY s8(d): 18 flop x (rays x n) / kernel time, against the 157.3 TFLOP/s FP32 vector peak the north star names; not executed arithmetic"},
         }
+        if not args.no_extras and world == 1:
+            out["other_workloads"] = other_workloads(ra, local_rank, table)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(table)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
