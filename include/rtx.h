@@ -111,7 +111,7 @@ int rtx_set_filter(rtx_ctx* ctx, int kind);
  * beside it, read once at rtx_create.  Unknown keys and out-of-range values fail with RTX_ERR_ARG.
  *   "block"          RTX_BLOCK           workgroup size, a multiple of 64 up to 512; 0 = automatic
  *   "stream"         RTX_STREAM          stream the MFMA filter's table through the LDS stage: -1 automatic, 0 never, 1 always
- *   "items_per_lane" RTX_ITEMS_PER_LANE  work items per lane that the smallest sample chunks are sized for (256)
+ *   "items_per_lane" RTX_ITEMS_PER_LANE  work items per lane that the smallest sample chunks are sized for (1024)
  *   "max_chunks"     RTX_MAX_CHUNKS      most sample chunks of an automatic plan (63)
  *   "tail_factor"    RTX_TAIL_FACTOR     how many mean item durations the plan allows a single item to take (30)
  *   "partials_mb"    RTX_PARTIALS_MB     cap of the partial-sum scratch (16 B per chunk and pixel) in MiB (1024)

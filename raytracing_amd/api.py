@@ -213,7 +213,7 @@ def random_scene(seed=1, grid_half=11, p_diffuse=0.8, p_metal=0.95):
     return np.stack([f[0][:n], f[1][:n], f[2][:n], f[3][:n], t[:n].astype(np.float32), f[4][:n], f[5][:n], f[6][:n], f[7][:n], f[8][:n]], axis=1)
 
 
-def plan_chunks(spp_count, n_pixels, lanes, items_per_lane=256, max_chunks=63, tail_factor=30, max_items=1 << 26):
+def plan_chunks(spp_count, n_pixels, lanes, items_per_lane=1024, max_chunks=63, tail_factor=30, max_items=1 << 26):
     """The automatic sample-chunk plan (rtx_plan_chunks): boundaries relative to spp_begin, first 0, last spp_count."""
     starts = np.zeros(64, dtype=np.uint32)
     n = C.c_uint32(0)
