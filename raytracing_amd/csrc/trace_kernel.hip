@@ -300,13 +300,14 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         float       closest = 3.402823466e+38f;                           // FLT_MAX, raytracer.cpp:251
         uint32_t    best = kNoHit;
         if constexpr (FILTER == kFilterGrid) {
-            // ---- Uniform grid (host side: rtx_host.cpp, build_grid).  Each lane walks the cells that its own
-            // ray crosses, in order, and runs the exact test of sphere.cpp:72-99 on the spheres registered there; the big list
-            // (spheres too large for the grid: the ground) is tested first, for every ray.  The winner is the minimum of
-            // (t, index) as everywhere else, so the order in which spheres are met does not matter, and a sphere met twice
-            // (it is registered in every cell it overlaps) changes nothing.  The walk stops early only when the closest hit so
-            // far lies more than the registration slack before the exit of the cell just finished: every hit point beyond that
-            // exit lies in a later cell or within the slack of this one's boundary, where its sphere was registered here too.
+            // ---- Uniform grid (host side and the argument why no hit is lost: rtx_host.cpp, build_grid).
+            // Each lane walks the cells that its own ray crosses, in order, and runs the exact test of sphere.cpp:72-99 on the
+            // spheres registered there; the big list (spheres too large for the grid: the ground) is tested first, for every ray.
+            // The winner is the minimum of (t, index) as everywhere else, so the order in which spheres are met does not matter,
+            // and a sphere met twice (it is registered in every cell it overlaps) changes nothing.  Registrations are grown by
+            // the blur of the reference's fp32 discriminant, in tiers by distance from the ray's origin; the walk stops early
+            // only when the closest hit so far lies more than twice the walk's own slack before the exit of the cell just
+            // finished (the accepted root of an untested sphere lies on its registered stretch of the ray, which starts later).
             // sphere.cpp:72-99 on geometry s; the sphere's index is only needed when the hit could become the closest one
             auto test = [&](const float4 s, auto index) {
                 lane_tests++;
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             bool scan_all = false;
             if (P.grid.dim[0] != 0u) {
                 const float inf = __builtin_inff();
-                const float slack_t = 2.0f * P.grid.pad * __builtin_amdgcn_rsqf(a);        // the registration slack as a ray parameter
+                const float slack_t = 2.0f * P.grid.pad * __builtin_amdgcn_rsqf(a);        // twice the walk's slack, as a ray parameter
                 // Is the origin within the registrations' reach?  If some binned sphere can be farther away than the outermost tier
                 // allows, the ray is clipped against the box grown by the blur of that distance and, if it enters, scans the table.
                 const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
@@ -366,8 +367,8 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 if (walking && far) { scan_all = true; walking = false; }
                 // Per axis: tn = parameter at which the ray leaves its current cell, dt = parameter per cell, the signed step of the
                 // linear cell index, and (10 bits each, packed in `rem`) how many cells are left before the ray leaves the grid.
-                // tn accumulates one rounding per step: at most 768 steps x 2^-24 of the largest parameter, a third of the
-                // registration pad (2^-12 of the extent), whose double is what the early stop leaves as slack.
+                // tn accumulates one rounding per step of its axis: at most 255 x 2^-24 of a parameter whose distance equivalent is
+                // at most far_l (two diagonals), i.e. a tenth of `pad` (2^-12 of the extent); the early stop leaves 2 pad.
                 float    tn[3], dt[3];
                 int      cstride[3];
                 uint32_t rem = 0u, cidx = 0u;
