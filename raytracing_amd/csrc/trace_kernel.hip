@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 // Per axis: tn = parameter at which the ray leaves its current cell, dt = parameter per cell, the signed step of the
                 // linear cell index, and (10 bits each, packed in `rem`) how many cells are left before the ray leaves the grid.
                 // tn accumulates one rounding per step of its axis: at most 255 x 2^-24 of a parameter whose distance equivalent is
-                // at most far_l (two diagonals), i.e. a tenth of `pad` (2^-12 of the extent); the early stop leaves 2 pad.
+                // at most far_l (two diagonals), i.e. under a quarter of `pad` (2^-12 of the extent); the early stop leaves 2 pad.
                 float    tn[3], dt[3];
                 int      cstride[3];
                 uint32_t rem = 0u, cidx = 0u;
