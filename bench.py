@@ -81,7 +81,7 @@ def other_workloads(ra, device, book1):
     BASELINE configuration 5 (20 164 spheres, 100 spp) with the linear list and with the uniform grid, and the
     bench scene with the grid.  Informational: `value` above is configuration 2 with the linear list."""
     out = {}
-    for name, table, spp in (("config5_20164_spheres_100spp", ra.random_scene(SEED, 71), 100), ("book1_100spp", book1, 100)):
+    for name, table, spp in (("config5_20164_spheres_100spp", ra.random_scene(SEED, 71), 100), ("config2_book1_500spp", book1, 500)):
         for fname, kind in (("linear_list_mfma", ra.FILTER_MFMA), ("uniform_grid", ra.FILTER_GRID)):
             ctx = ra.Context(device)
             try:

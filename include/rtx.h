@@ -64,9 +64,9 @@ enum {
 enum { RTX_FILTER_VALU = 0, RTX_FILTER_MFMA = 1,
        RTX_FILTER_GRID = 2   /* an acceleration structure instead of a filter over the whole list: a uniform grid
                                 over the table, walked per ray; spheres too large for it are tested for every ray.  For large
-                                tables (faster than the MFMA filter from about 750 spheres); the linear list of the
+                                tables (faster than the MFMA filter from about 300 spheres); the linear list of the
                                 reference is RTX_FILTER_MFMA */,
-       RTX_FILTER_AUTO = 3   /* RTX_FILTER_MFMA below 768 spheres, RTX_FILTER_GRID from there on */ };
+       RTX_FILTER_AUTO = 3   /* RTX_FILTER_MFMA up to 256 spheres, RTX_FILTER_GRID from there on */ };
 
 /* Counters gathered inside the kernel with wave ballots (rays = _sceneHit calls, raytracer.cpp:251). */
 typedef struct rtx_stats {

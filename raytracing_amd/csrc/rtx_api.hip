@@ -435,8 +435,9 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
     if (R.fill_only) return RTX_OK;
 
     R.filter = c->filter;
-    // RTX_FILTER_AUTO: the linear list through the MFMA filter while it is the faster one, the grid above (on book-1-like scenes the two
-    // cross near 750 spheres: 485 spheres 7 575 against 6 022 Msamples/s, 1 601 spheres 3 004 against 4 570, profiles/r02c_grid_filter.txt)
+    // RTX_FILTER_AUTO: the linear list through the MFMA filter while it is the faster one, the grid above: up to 256 spheres (two
+    // 128-sphere groups) the MFMA filter leads by 3-15 %, from 327 spheres on the grid does (485: 8 732 against 7 275 Msamples/s,
+    // 1 601: 8 034 against 3 126; tools/filter_crossover.py, profiles/r02c_grid_filter.txt)
     if (R.filter == kFilterAuto) R.filter = c->n >= kAutoGridSpheres ? kFilterGrid : kFilterMfma;
     if (R.filter == kFilterMfma) {
         // primary rays start on the lens (camera.h:75-86); bounce rays start on spheres, which the scale already covers

@@ -32,7 +32,7 @@ constexpr double   kMfmaAbsMargin = 0.03125;                         // 2^-5
 constexpr float    kGammaRay   = 1.52587890625e-05f * 1.0625f;   // 2^-16 plus room for the rounding of |o|^2 itself
 constexpr double   kGammaSphere = 1.52587890625e-05;
 enum FilterKind { kFilterValu = 0, kFilterMfma = 1, kFilterGrid = 2, kFilterAuto = 3 };   // kFilterAuto is a host-side choice, never a kernel variant
-constexpr uint32_t kAutoGridSpheres = 768u;
+constexpr uint32_t kAutoGridSpheres = 257u;
 // where the filter's sphere table lives: read through L2 by every wave, resident in LDS, or (MFMA filter) streamed
 // through a double-buffered LDS stage that the waves of a workgroup fill together, 128 spheres at a time
 enum TableMode { kTableGlobal = 0, kTableLds = 1, kTableStream = 2 };

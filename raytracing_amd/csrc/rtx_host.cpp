@@ -136,6 +136,7 @@ void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* 
     for (int t = 0; t < 3; ++t) { G.tier_l[t] = 0.0; G.tier_grow[t] = 0.0; }
     std::vector<uint32_t> cand;
     std::vector<uint8_t>  is_big(n, 0);
+    uint32_t n_wide = 0;                          // spheres put on the big list for being wide, not huge
     for (int round = 0; round < 8; ++round) {
         // bounds of the spheres that are (still) meant for the grid
         double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 }, r_max = 0.0;
@@ -194,6 +195,20 @@ void rtx::build_grid(uint32_t n, const float* cx, const float* cy, const float* 
             uint64_t cells = 1;
             for (int k = 0; k < 3; ++k) cells *= (uint64_t)std::min<double>(dim[k], std::floor(2.0 * r / hk[k]) + 2.0);
             if (cells > kBigCells) { is_big[i] = 1; changed = true; }
+        }
+        // A few spheres much larger than the rest also go on the big list: there a sphere costs one test per ray with all lanes
+        // busy (about one wave-instruction per ray); in the grid it is tested in every one of its cells that a ray crosses, at the
+        // walk's lane utilisation -- and it can multiply the grid's thin extent (book-1's three unit spheres over a field of
+        // r = 0.2 make a second layer of cells that rays cross without meeting anything: 82 against 50 ms per 500 spp).  Outliers
+        // are radii above 2.5 medians, the 16 largest at most.
+        if (!changed && n_wide < 16u) {
+            std::vector<uint32_t> order(cand);
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return std::fabs(radius[x]) > std::fabs(radius[y]); });
+            const double median = std::fabs((double)radius[order[order.size() / 2]]);
+            for (uint32_t i : order) {
+                if (n_wide >= 16u || !(std::fabs((double)radius[i]) > 2.5 * median)) break;
+                is_big[i] = 1; changed = true; ++n_wide;
+            }
         }
         if (changed) continue;                    // their removal may shrink the bounds a lot (the ground sphere): again
         GridDesc& D = G.desc;

@@ -293,7 +293,7 @@ def test_grid_filter_degenerate_tables(ra, oracle):
 
 
 def test_auto_filter_picks_by_table_size(ra, golden_scenes):
-    """RTX_FILTER_AUTO is the MFMA filter below 768 spheres and the grid from there on: same image either way, and the
+    """RTX_FILTER_AUTO is the MFMA filter up to 256 spheres and the grid from there on: same image either way, and the
     number of exact tests tells which one ran; the grid's density knob changes which spheres reach the exact test and nothing else."""
     cols, rows, spp = 96, 64, 2
     args = (20.0, np.float32(cols) / np.float32(rows), 0.1, 10.0, (13, 2, 3), (0, 1, 0), (0, 0, 0))
@@ -311,15 +311,16 @@ def test_auto_filter_picks_by_table_size(ra, golden_scenes):
         finally:
             ctx.close()
 
-    for name, expect in (("book1", ra.FILTER_MFMA), ("scaled", ra.FILTER_GRID)):
-        table = golden_scenes[name]
-        assert (len(table) >= 768) == (expect == ra.FILTER_GRID)
+    for table, expect in ((ra.random_scene(1, 5), ra.FILTER_MFMA), (golden_scenes["book1"], ra.FILTER_GRID), (golden_scenes["scaled"], ra.FILTER_GRID)):
+        assert (len(table) > 256) == (expect == ra.FILTER_GRID)
         a_auto, s_auto = run(table, ra.FILTER_AUTO)
         a_ref, s_ref = run(table, expect)
         other = ra.FILTER_GRID if expect == ra.FILTER_MFMA else ra.FILTER_MFMA
         a_other, s_other = run(table, other)
         assert (bits(a_auto) == bits(a_ref)).all() and (bits(a_auto) == bits(a_other)).all()
-        assert s_auto["candidates"] == s_ref["candidates"] != s_other["candidates"]
+        # which one ran: the number of exact tests (the grid's varies a little from launch to launch: its straggler mode
+        # depends on which rays share a wave at the time)
+        assert abs(s_auto["candidates"] - s_ref["candidates"]) < 0.05 * s_ref["candidates"] < 0.25 * abs(s_auto["candidates"] - s_other["candidates"])
     table = golden_scenes["scaled"]
     a_coarse, s_coarse = run(table, ra.FILTER_GRID, density=400)
     a_fine, s_fine = run(table, ra.FILTER_GRID, density=12)
