@@ -29,9 +29,11 @@ def _hip_frame(ra, ctx, table, f, chunk):
     return ctx.read_accum(), primary, st
 
 
-def test_golden_frames_bit_exact(ra, ctx, golden_scenes, golden_frames):
+@pytest.mark.parametrize("filt", ["mfma", "valu", "grid"])
+def test_golden_frames_bit_exact(ra, ctx, golden_scenes, golden_frames, filt):
     """Primary-hit indices, colour sums and 8-bit framebuffers equal what the compiled reference produced (the -r frame
-    included: raytracer.cpp:213-240 multiplies the attenuations innermost first)."""
+    included: raytracer.cpp:213-240 multiplies the attenuations innermost first), whichever way the candidates are found."""
+    ctx.set_filter({"mfma": ra.FILTER_MFMA, "valu": ra.FILTER_VALU, "grid": ra.FILTER_GRID}[filt])
     for name, f in golden_frames.items():
         accum, primary, st = _hip_frame(ra, ctx, golden_scenes[f["scene"]], f, f["spp_count"])
         if "primary" in f:
@@ -97,13 +99,14 @@ def test_psnr_against_unmodified_reference_render(ra, ctx, oracle, golden_scenes
     assert psnr >= 40.0, (name, psnr, rmse)
 
 
-@pytest.mark.parametrize("scene", ["book1", "glass"])
-def test_benchmark_frame_primary_hits_and_image(ra, ctx, oracle, golden_scenes, scene):
+@pytest.mark.parametrize("scene,filt", [("book1", "mfma"), ("glass", "mfma"), ("book1", "grid"), ("scaled", "grid"), ("scaled", "mfma")])
+def test_benchmark_frame_primary_hits_and_image(ra, ctx, oracle, golden_scenes, scene, filt):
     """north_star's first bar on the BENCHMARK frame itself: 1200x800, depth 50 -- the sphere index of
     every primary hit (raytracer.cpp:285-304, lowest index on ties), the colour sums, the counters and the 8-bit
     framebuffer equal the oracle's, which runs the same 960 000 paths on the host cores."""
     cols, rows, spp = 1200, 800, 1
     table = golden_scenes[scene]
+    ctx.set_filter(ra.FILTER_GRID if filt == "grid" else ra.FILTER_MFMA)      # the production (non-validating) kernels of both
     ctx.upload_scene(table)
     ctx.set_camera(ra.book_camera(cols, rows))
     primary, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=spp, want_primary=True)
