@@ -257,7 +257,8 @@ int rtx_plan_chunks(uint32_t spp_count, uint64_t n_pixels, uint64_t lanes, uint3
  * registers a sphere wherever its bounding box grown by pad + blur(r, tier_l[k]) reaches (the reference's fp32 sphere test
  * accepts rays that pass a sphere at up to blur(r, L) = sqrt(r^2 + 2^-19 (L^2 + r^2)) - r beyond its surface when the ray's
  * origin is L away); a ray reads the parts 0..k of its cells when it cannot get farther than tier_s[k] (k = 0, 1) from its
- * origin inside the grid; tier_s[2] = tier_l[2] is the distance beyond which the table is scanned instead. */
+ * origin inside the grid; tier_s[2] = tier_l[2]: when the origin's distance from the box + box_diag exceeds it, the ray is clipped
+ * against the box grown by pad + blur(r_min, that distance) and, if it enters, scans the table instead. */
 typedef struct rtx_grid_info {
     float    gmin[3], inv_h[3], h[3];
     uint32_t dim[3];
@@ -266,6 +267,7 @@ typedef struct rtx_grid_info {
     uint64_t n_items;
     float    tier_s[3];
     double   tier_l[3], tier_grow[3];
+    float    box_diag, r_min;      /* diagonal of the grid box; smallest binned radius */
 } rtx_grid_info;
 int rtx_build_grid(uint32_t n, const float* cx, const float* cy, const float* cz, const float* radius, uint32_t density_pct,
                    rtx_grid_info* info, uint32_t* cell_start, uint64_t cell_start_cap, uint32_t* items, uint64_t items_cap,

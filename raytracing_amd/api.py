@@ -45,7 +45,7 @@ class GridInfo(C.Structure):
     """rtx_grid_info: the uniform grid of FILTER_GRID (rtx_build_grid)."""
     _fields_ = [("gmin", C.c_float * 3), ("inv_h", C.c_float * 3), ("h", C.c_float * 3), ("dim", C.c_uint32 * 3),
                 ("pad", C.c_float), ("n_big", C.c_uint32), ("n_items", C.c_uint64), ("tier_s", C.c_float * 3),
-                ("tier_l", C.c_double * 3), ("tier_grow", C.c_double * 3)]
+                ("tier_l", C.c_double * 3), ("tier_grow", C.c_double * 3), ("box_diag", C.c_float), ("r_min", C.c_float)]
 
 
 _lib = None
@@ -239,7 +239,8 @@ def build_grid(table, density_pct=35):
     return {"gmin": np.array(info.gmin[:], dtype=np.float32), "h": np.array(info.h[:], dtype=np.float32), "inv_h": np.array(info.inv_h[:], dtype=np.float32),
             "dim": np.array(info.dim[:], dtype=np.int64), "pad": float(info.pad), "cell_start": cell_start, "items": items[:info.n_items], "big": big[:info.n_big],
             "tier_end": tier_end[:3 * ncell].reshape(-1, 3), "tier_s": np.array(info.tier_s[:], dtype=np.float32),
-            "tier_l": np.array(info.tier_l[:]), "tier_grow": np.array(info.tier_grow[:])}
+            "tier_l": np.array(info.tier_l[:]), "tier_grow": np.array(info.tier_grow[:]),
+            "box_diag": np.float32(info.box_diag), "r_min": np.float32(info.r_min)}
 
 
 def write_ppm(path, cols, rows, framebuffer, binary=False):

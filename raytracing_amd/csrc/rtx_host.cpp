@@ -275,6 +275,7 @@ extern "C" int rtx_build_grid(uint32_t n, const float* cx, const float* cy, cons
     rtx::build_grid(n, cx, cy, cz, radius, density_pct / 100.0, &G);
     for (int k = 0; k < 3; ++k) { info->gmin[k] = G.desc.gmin[k]; info->inv_h[k] = G.desc.inv_h[k]; info->h[k] = G.desc.h[k]; info->dim[k] = G.desc.dim[k]; }
     info->pad = G.desc.pad; info->n_big = G.desc.n_big; info->n_items = G.items.size();
+    info->box_diag = G.desc.box_diag; info->r_min = G.desc.r_min;
     for (int t = 0; t < 3; ++t) { info->tier_s[t] = t < 2 ? G.desc.tier_s[t] : G.desc.far_l; info->tier_l[t] = G.tier_l[t]; info->tier_grow[t] = G.tier_grow[t]; }
     if (cell_start) { if (cell_start_cap < G.cell_start.size()) return RTX_ERR_ARG; std::copy(G.cell_start.begin(), G.cell_start.end(), cell_start); }
     if (items)      { if (items_cap < G.items.size()) return RTX_ERR_ARG; std::copy(G.items.begin(), G.items.end(), items); }
