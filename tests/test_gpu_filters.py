@@ -275,8 +275,21 @@ def test_grid_filter_degenerate_tables(ra, oracle):
         "huge": np.array([[0, -1000, 0, 1000, 1, .5, .5, .5, 1, 1], [0, 1000.5, 0, 999, 2, .8, .8, .8, 0, 1], [2000, 0, 0, 1990, 3, 1, 1, 1, 0, 1.5]], dtype=np.float32),
         "zero_radius": np.array([[0, 0, 0, 0.0, 1, .5, .5, .5, 1, 1], [1, 0, 0, 0.5, 2, .5, .5, .5, 0.2, 1], [0, -100.5, 0, 100, 1, .3, .6, .3, 1, 1]], dtype=np.float32),
     }
+    rng = np.random.default_rng(8)
+    line = np.zeros((300, 10), dtype=np.float32)                     # a one-dimensional grid
+    line[:, 0] = np.linspace(-30, 30, 300); line[:, 3] = 0.08; line[:, 4] = 1; line[:, 5:8] = 0.6; line[:, 9] = 1
+    cases["line"] = line
+    cloud = np.zeros((400, 10), dtype=np.float32)                    # a three-dimensional one, radii over two decades, some negative
+    cloud[:, 0:3] = rng.uniform(-4, 4, size=(400, 3)); cloud[:, 3] = 10.0 ** rng.uniform(-2.5, -0.5, 400) * rng.choice([1, 1, 1, -1], 400)
+    cloud[:, 4] = rng.integers(1, 4, 400); cloud[:, 5:8] = 0.7; cloud[:, 8] = 0.1; cloud[:, 9] = 1.5
+    cases["cloud"] = cloud
+    shifted = cloud.copy()                                           # the same far from the coordinate origin: the slack follows the coordinates
+    shifted[:, 0:3] += np.float32(3.0e4)
+    cases["shifted"] = shifted
     args = (40.0, np.float32(cols) / np.float32(rows), 0.05, 6.0, np.array([3, 1.5, 5], dtype=np.float32), (0, 1, 0), (0, 0, 0))
     for name, table in cases.items():
+        if name == "shifted":
+            args = (40.0, np.float32(cols) / np.float32(rows), 0.05, 6.0, np.array([3, 1.5, 5], dtype=np.float32) + np.float32(3.0e4), (0, 1, 0), (3.0e4, 3.0e4, 3.0e4))
         ctx = ra.Context(0)
         try:
             ctx.set_filter(ra.FILTER_GRID)
