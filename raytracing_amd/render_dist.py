@@ -34,6 +34,7 @@ def parse(argv):
     ap.add_argument("-k", default="")
     ap.add_argument("-R", action="store_true")
     ap.add_argument("-6", dest="p6", action="store_true")
+    ap.add_argument("-F", default="", choices=["", "valu", "mfma", "grid", "auto"])   # candidate search, as rtx_cli -F (results are identical)
     ap.add_argument("--help", action="help")
     a = ap.parse_args(argv)
     if a.R and not a.k:
@@ -69,6 +70,8 @@ def main(argv=None):
     flags = ra.FLAG_RECURSIVE if a.r else 0
     table = ra.random_scene(seed, *VARIANTS[a.n])
     ctx = ra.Context(local_rank)
+    if a.F:
+        ctx.set_filter({"valu": ra.FILTER_VALU, "mfma": ra.FILTER_MFMA, "grid": ra.FILTER_GRID, "auto": ra.FILTER_AUTO}[a.F])
     ctx.upload_scene(table)
     ctx.set_camera(ra.book_camera(cols, rows))
     accum = TorchAccum(ctx, cols, rows, dev)

@@ -60,7 +60,7 @@ def test_render_dist_matches_rtx_cli_and_resumes(tmp_path):
     a, b, ck = tmp_path / "a.ppm", tmp_path / "b.ppm", tmp_path / "b.accum"
     r = subprocess.run([cli] + common + ["-a", "6", "-f", str(a)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    r = subprocess.run(dist_cmd + ["-a", "4", "-f", str(b), "-k", str(ck)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    r = subprocess.run(dist_cmd + ["-a", "4", "-f", str(b), "-k", str(ck), "-F", "auto"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0 and r.stdout.count("pass done") == 2 and ck.exists(), r.stdout + r.stderr
     # resumed by the C++ host: the checkpoint format is shared
     r = subprocess.run([cli] + common + ["-a", "6", "-f", str(b), "-k", str(ck), "-R"], capture_output=True, text=True, timeout=120)
