@@ -205,7 +205,8 @@ int rtx_resolve_rgbx8(rtx_ctx* ctx, uint32_t spp_total, uint32_t debug_tile, uin
  * place.  Invariant: the SUM over the members' buffers is the image's colour sum -- after the exchange member 0 holds the
  * total and the others are zeroed, so RTX_FLAG_ACCUMULATE passes and further exchanges count every sample once.
  * A group of one device is rtx_render bit for bit (its exchange is the identity and RCCL is not initialised).
- * All calls block.  Members can be tuned individually through rtx_group_member. */
+ * All calls block.  Members can be tuned individually through rtx_group_member.  Rehearsal on a one-GPU box: with
+ * RTX_GROUP_LOOPBACK=1 in the environment the ids may all name the same device and the exchange is a plain sum into member 0. */
 typedef struct rtx_group rtx_group;
 int rtx_group_create(const int* device_ids, int n_devices, rtx_group** out_group);
 int rtx_group_destroy(rtx_group* group);

@@ -799,7 +799,15 @@ extern "C" int rtx_resolve_rgbx8(rtx_ctx* c, uint32_t spp_total, uint32_t debug_
 struct rtx_group {
     std::vector<rtx_ctx*>   members;
     std::vector<ncclComm_t> comms;        // empty for a group of one: its all-reduce is the identity
+    bool                    loopback = false;   // RTX_GROUP_LOOPBACK=1: several members on ONE device, exchange without RCCL (rehearsal)
 };
+
+// the exchange of a loopback group: dst += src (same device)
+static __global__ void __launch_bounds__(256) accum_add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = dst[i] + src[i];
+}
 
 #define NCCL_TRY(expr)                                                                                         \
     do {                                                                                                       \
@@ -834,11 +842,20 @@ extern "C" int rtx_group_create(const int* device_ids, int n_devices, rtx_group*
     if (!out) return fail(RTX_ERR_ARG, "rtx_group_create: out is NULL");
     *out = nullptr;
     if (!device_ids || n_devices < 1 || n_devices > 64) return fail(RTX_ERR_ARG, "rtx_group_create: need 1..64 device ids");
+    // RTX_GROUP_LOOPBACK=1: a rehearsal of groups of several members on a box with one GPU -- every id must name the same
+    // device, the members render their shares one after another on it and the exchange is a plain sum into member 0 (no
+    // RCCL: it refuses two ranks on one device).  Everything else -- the split, the invariant, progressive passes -- is the
+    // code that a multi-GPU group runs.
+    const char* lb = getenv("RTX_GROUP_LOOPBACK");
+    const bool  loopback = lb && atoi(lb) != 0 && n_devices > 1;
     for (int i = 0; i < n_devices; ++i)
-        for (int j = 0; j < i; ++j)
-            if (device_ids[i] == device_ids[j]) return fail(RTX_ERR_ARG, "rtx_group_create: device %d is listed twice", device_ids[i]);
+        for (int j = 0; j < i; ++j) {
+            if (!loopback && device_ids[i] == device_ids[j]) return fail(RTX_ERR_ARG, "rtx_group_create: device %d is listed twice", device_ids[i]);
+            if (loopback && device_ids[i] != device_ids[j]) return fail(RTX_ERR_ARG, "rtx_group_create: RTX_GROUP_LOOPBACK needs every member on the same device");
+        }
     rtx_group* g = new (std::nothrow) rtx_group();
     if (!g) return fail(RTX_ERR_NOMEM, "rtx_group_create: out of host memory");
+    g->loopback = loopback;
     g->members.assign((size_t)n_devices, nullptr);
     for (int i = 0; i < n_devices; ++i) {
         const int rc = rtx_create(device_ids[i], &g->members[(size_t)i]);
@@ -847,7 +864,7 @@ extern "C" int rtx_group_create(const int* device_ids, int n_devices, rtx_group*
     // RTX_GROUP_RCCL=1 makes a group of ONE device go through RCCL too (a communicator of one rank): the rehearsal of the
     // exchange on a single-GPU box; without it a group of one never touches RCCL
     const char* force = getenv("RTX_GROUP_RCCL");
-    if (n_devices > 1 || (force && atoi(force) != 0)) {
+    if (!loopback && (n_devices > 1 || (force && atoi(force) != 0))) {
         g->comms.assign((size_t)n_devices, nullptr);
         const ncclResult_t r = ncclCommInitAll(g->comms.data(), n_devices, device_ids);
         if (r != ncclSuccess) {
@@ -956,6 +973,19 @@ extern "C" int rtx_group_allreduce(rtx_group* g)
     const size_t count = (size_t)c0->cols * c0->rows * 3;
     for (rtx_ctx* c : g->members)
         if (!c->accum || (size_t)c->cols * c->rows * 3 != count) return fail(RTX_ERR_STATE, "rtx_group_allreduce: the members hold images of different sizes");
+    if (g->loopback) {
+        // member 0's buffer takes the others' in member order, behind everybody's kernels; then the invariant as below
+        HIP_TRY(hipSetDevice(c0->device));
+        for (rtx_ctx* c : g->members) HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 1; i < world; ++i) {
+            accum_add_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c0->stream>>>(c0->accum, g->members[i]->accum, count);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(c0->stream));
+        for (size_t i = 1; i < world; ++i) HIP_TRY(hipMemsetAsync(g->members[i]->accum, 0, count * sizeof(float), g->members[i]->stream));
+        for (rtx_ctx* c : g->members) HIP_TRY(hipStreamSynchronize(c->stream));
+        return RTX_OK;
+    }
     if (g->comms.empty()) return RTX_OK;                         // a group of one: the sum over one buffer
     // one collective: sum of rows*cols*3 floats (11.5 MB at 1200 x 800, 99.5 MB at 3840 x 2160), in place, each rank's part
     // on that member's own stream, i.e. behind its trace and reduce kernels

@@ -2,7 +2,8 @@
 bit, with and without RCCL in the loop (RTX_GROUP_RCCL=1 builds a communicator of one rank, so ncclCommInitAll and
 ncclAllReduce really execute); the C++ wrapper and rtx_cli -G go through the same calls.  Groups of more than one device
 need a multi-GPU node: the sample split they use is checked on the host (tests/test_host_cabi.py) and the sum across
-ranks by the 2-rank gloo tests; N > 1 is UNMEASURED on hardware until the driver's scaling run.  Needs an MI355X."""
+ranks by the 2-rank gloo tests; groups of 2-4 MEMBERS run here in loopback on the one device (RTX_GROUP_LOOPBACK=1, no RCCL);
+N > 1 DEVICES is UNMEASURED on hardware until the driver's scaling run.  Needs an MI355X."""
 import os
 import subprocess
 import sys
@@ -105,3 +106,49 @@ def test_cli_gpu_count_flag(tmp_path, ra, oracle, golden_scenes):
     assert ((px[:, 0] << 24 | px[:, 1] << 16 | px[:, 2] << 8) == fb).all()
     r = subprocess.run([cli, "-g", "-G", "0", "-f", str(out)], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0
+
+
+def test_groups_of_two_and_three_members_in_loopback(golden_scenes):
+    """RTX_GROUP_LOOPBACK=1: groups of SEVERAL members on the one GPU of a test box (the exchange is a plain sum into member 0,
+    everything else is the multi-GPU code): the sample split, the per-member launches, the sum, the zeroing of the other
+    members, progressive passes and the statistics.  With the members' ranges as the chunks of a single launch the sums are
+    added in the same order, so the group's image equals rtx_render's bit for bit."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import raytracing_amd as ra
+table = np.load(%r)["book1"]
+cols, rows, seed = 120, 80, 3
+cam = ra.book_camera(cols, rows)
+for world, spp in ((2, 8), (3, 9), (3, 8), (4, 2)):
+    per = [ra.spp_range(r, world, 0, spp) for r in range(world)]
+    g = ra.Group([0] * world); g.upload_scene(table); g.set_camera(cam)
+    st = g.render(cols, rows, 0, spp, 50, seed, chunk_spp=spp)          # every member: its share as one chunk
+    g.allreduce()
+    got, fb = g.member(0).read_accum(), g.resolve(spp)
+    for r in range(1, world):
+        assert not g.member(r).read_accum().any()                       # the invariant: the sum over the members is the image
+    # the same sums in the same order on one context: one launch per share, accumulated
+    ctx = ra.Context(0); ctx.upload_scene(table); ctx.set_camera(cam)
+    tot = dict(samples=0, rays=0)
+    for k, (b, c) in enumerate(per):
+        if c == 0:
+            continue
+        _, s1 = ctx.render(cols, rows, b, c, 50, seed, flags=ra.FLAG_ACCUMULATE if k else 0, chunk_spp=c)
+        tot["samples"] += s1["samples"]; tot["rays"] += s1["rays"]
+    want, want_fb = ctx.read_accum(), ctx.resolve(spp)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all() and (fb == want_fb).all(), (world, spp)
+    assert st["samples"] == tot["samples"] == cols * rows * spp and st["rays"] == tot["rays"]
+    # a second, accumulating pass after the exchange counts every sample once
+    g.render(cols, rows, spp, 4, 50, seed, flags=ra.FLAG_ACCUMULATE, chunk_spp=4, want_stats=False)
+    g.allreduce()
+    for k, (b, c) in enumerate(ra.spp_range(r, world, spp, 4) for r in range(world)):
+        if c:
+            ctx.render(cols, rows, b, c, 50, seed, flags=ra.FLAG_ACCUMULATE, chunk_spp=c, want_stats=False)
+    assert (g.member(0).read_accum().view(np.uint32) == ctx.read_accum().view(np.uint32)).all(), (world, "second pass")
+    ctx.close(); g.close()
+print("loopback groups ok")
+''' % (ROOT, os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+    env = dict(os.environ, RTX_GROUP_LOOPBACK="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "loopback groups ok" in r.stdout, r.stdout + r.stderr
