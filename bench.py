@@ -142,7 +142,13 @@ def main():
         local_rank %= torch.cuda.device_count()      # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RTX_DIST_BACKEND=gloo: a rehearsal of the N > 1 code on a box with fewer GPUs than ranks (ranks share devices, the sum
+        # goes through the host: the number it prints is not a measurement); the driver's runs use "nccl" = RCCL over xGMI
+        backend = os.environ.get("RTX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cols, rows, spp = args.cols, args.rows, args.spp
     table = ra.random_scene(SEED)
@@ -211,7 +217,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("book-1 final scene (seed 1, %d spheres) %dx%d, %d spp in all, depth %d" if args.strong else "book-1 final scene (seed 1, %d spheres) %dx%d, %d spp per GPU, depth %d") % (len(table), cols, rows, spp_total if args.strong else spp, DEPTH),
-                       "parallelism": "spp split x%d + RCCL all-reduce of the float accumulation buffer" % world if world > 1 else "1 GPU",
+                       "parallelism": ("spp split x%d + RCCL all-reduce of the float accumulation buffer" % world if os.environ.get("RTX_DIST_BACKEND", "nccl") == "nccl" else "REHEARSAL: %d ranks over %d device(s), %s all-reduce" % (world, torch.cuda.device_count(), os.environ["RTX_DIST_BACKEND"])) if world > 1 else "1 GPU",
                        "rays_per_sample": round(stats["rays"] / stats["samples"], 4)},
             # What the hardware executes for the sphere loop is the f16 MFMA filter: that is the roofline this line is priced
             # against (achieved = filter flop issued on the matrix cores / measured kernel time; dense f16 peak).  The kernel's

@@ -64,7 +64,13 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RTX_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share devices, the sum goes through the
+        # host); the product path is "nccl" = RCCL over xGMI
+        backend = os.environ.get("RTX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cols, rows, spp, depth, seed = a.w, a.h, a.a, a.m, a.s
     flags = ra.FLAG_RECURSIVE if a.r else 0

@@ -91,3 +91,29 @@ def test_cli_filter_flag(tmp_path):
     assert all(img == images[0] for img in images[1:])
     r = subprocess.run(base + ["-F", "bvh", "-f", str(tmp_path / "x.ppm")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "-F takes" in r.stdout
+
+
+def test_two_ranks_share_the_gpu_in_rehearsal(tmp_path):
+    """The one-process-per-GPU hosts with TWO ranks on the one GPU of a test box (RTX_DIST_BACKEND=gloo: the sum goes through
+    the host instead of RCCL, everything else is the N > 1 code): render_dist's image equals the one-rank image up to the
+    order of the float sums (at most one 8-bit step in a few channels), and bench.py prints its line for --gpus 2."""
+    import json
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, RTX_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    common = ["-w", "96", "-h", "64", "-m", "8", "-s", "2", "-a", "12", "-p", "4", "-6"]
+    a, b = tmp_path / "one.ppm", tmp_path / "two.ppm"
+    r = subprocess.run([sys.executable, "-m", "raytracing_amd.render_dist"] + common + ["-f", str(a)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29617"]
+    r = subprocess.run(launch + ["-m", "raytracing_amd.render_dist"] + common + ["-f", str(b)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pa, pb = np.frombuffer(open(a, "rb").read()[-96 * 64 * 3:], dtype=np.uint8).astype(int), np.frombuffer(open(b, "rb").read()[-96 * 64 * 3:], dtype=np.uint8).astype(int)
+    assert np.abs(pa - pb).max() <= 1 and (pa != pb).mean() < 0.01
+    r = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "8", "--cols", "160", "--rows", "100"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "REHEARSAL" in line["config"]["parallelism"]
+    assert line["value"] > 0 and "cpu_baseline" not in line and "other_workloads" not in line
