@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace pk
@@ -63,7 +64,10 @@ inline int renderSceneHIP(const Scene& scene, const Camera& camera, unsigned row
     const uint32_t flags = recursive ? RTX_FLAG_RECURSIVE : 0u;
     // a group of n_devices member contexts; a group of one is a plain context (no RCCL involved)
     std::vector<int> devs;
-    for (int d = 0; d < (opt.n_devices > 0 ? opt.n_devices : 1); ++d) devs.push_back(opt.device + d);
+    // RTX_GROUP_LOOPBACK=1 (rehearsal on a one-GPU box, see rtx_group_create): every member on the first device
+    const char* loopback = getenv("RTX_GROUP_LOOPBACK");
+    const bool  same_device = loopback && atoi(loopback) != 0;
+    for (int d = 0; d < (opt.n_devices > 0 ? opt.n_devices : 1); ++d) devs.push_back(same_device ? opt.device : opt.device + d);
     rtx_group* grp = nullptr;
     int rc = rtx_group_create(devs.data(), (int)devs.size(), &grp);
     rtx_ctx* ctx = rc == RTX_OK ? rtx_group_member(grp, 0) : nullptr;

@@ -152,3 +152,31 @@ print("loopback groups ok")
     env = dict(os.environ, RTX_GROUP_LOOPBACK="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "loopback groups ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_cli_with_three_members_in_loopback(tmp_path):
+    """rtx_cli -G 3 under RTX_GROUP_LOOPBACK=1: the C++ wrapper's multi-member path (split, exchange per pass, checkpoint of the
+    sum on member 0, resume with the other members zeroed) on the one GPU.  The image equals -G 1's up to the order of the
+    float sums; a render resumed from its checkpoint equals the uninterrupted one exactly."""
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    env = dict(os.environ, RTX_GROUP_LOOPBACK="1")
+    base = [cli, "-w", "96", "-h", "64", "-m", "8", "-s", "4", "-6"]
+
+    def pixels(path):
+        return np.frombuffer(open(path, "rb").read()[-96 * 64 * 3:], dtype=np.uint8).astype(int)
+
+    one, three, part, ck = tmp_path / "one.ppm", tmp_path / "three.ppm", tmp_path / "part.ppm", tmp_path / "c.accum"
+    r = subprocess.run(base + ["-G", "1", "-a", "12", "-f", str(one)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(base + ["-G", "3", "-a", "12", "-p", "6", "-f", str(three)], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and r.stdout.count("pass done") == 2, r.stdout + r.stderr
+    assert np.abs(pixels(one) - pixels(three)).max() <= 1 and (pixels(one) != pixels(three)).mean() < 0.01
+    # stopped after one pass, then resumed by three members from the checkpoint
+    r = subprocess.run(base + ["-G", "3", "-a", "6", "-p", "6", "-k", str(ck), "-f", str(part)], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and ck.exists(), r.stdout + r.stderr
+    r = subprocess.run(base + ["-G", "3", "-a", "12", "-p", "6", "-k", str(ck), "-R", "-f", str(part)], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "resuming" in r.stdout and r.stdout.count("pass done") == 1, r.stdout + r.stderr
+    assert open(part, "rb").read() == open(three, "rb").read()
+    # without the rehearsal switch a second GPU is really asked for
+    r = subprocess.run(base + ["-G", "3", "-a", "2", "-f", str(part)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
