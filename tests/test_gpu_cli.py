@@ -117,3 +117,11 @@ def test_two_ranks_share_the_gpu_in_rehearsal(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "REHEARSAL" in line["config"]["parallelism"]
     assert line["value"] > 0 and "cpu_baseline" not in line and "other_workloads" not in line
+    weak_samples = line["value"] * line["ms_per_step"]
+    # --strong: the image's 9 samples split 5 + 4 over the ranks (BASELINE's 500 spp over 8 GPUs is timed this way)
+    r = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "9", "--cols", "160", "--rows", "100", "--strong"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and "9 spp in all" in line["config"]["workload"]
+    assert abs(line["value"] * line["ms_per_step"] / (160 * 100 * 9 / 1e3) - 1.0) < 1e-3 and abs(weak_samples / (160 * 100 * 16 / 1e3) - 1.0) < 1e-3
