@@ -343,19 +343,22 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     const float off = fmaxf(fmaxf(lo - oo[k], oo[k] - hi), 0.0f);
                     s_near2 += off * off;
                 }
-                const float l_far = sqrtf(s_near2) * 1.000001f + P.grid.box_diag;
+                // (the walk only needs conservative values here: hardware sqrt / rcp, 1 ulp, with margins of 1e-5 -- its results do not depend on them)
+                const float l_far = __builtin_amdgcn_sqrtf(s_near2) * 1.00001f + P.grid.box_diag;
                 const bool  far   = !(l_far <= P.grid.far_l);                               // also NaN
                 const float rm    = P.grid.r_min;
-                const float extra = far ? P.grid.pad + (sqrtf(rm * rm + 1.9073486328125e-6f * (l_far * l_far + rm * rm)) * 1.000001f - rm) : 0.0f;
+                const float extra = far ? P.grid.pad + (__builtin_amdgcn_sqrtf(rm * rm + 1.9073486328125e-6f * (l_far * l_far + rm * rm)) * 1.00001f - rm) : 0.0f;
                 // slab clip of the ray against the grid box; a zero component of d leaves that axis unbounded when the origin is inside
                 float    t_in = 0.0f, t_out = inf;
                 bool     walking = tracing;
                 float    inv[3];
+                bool     moving[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float lo = P.grid.gmin[k] - extra, hi = P.grid.gmin[k] + (float)P.grid.dim[k] * P.grid.h[k] + extra;
-                    inv[k] = 1.0f / dd[k];
-                    if (dd[k] != 0.0f) {
+                    inv[k] = __builtin_amdgcn_rcpf(dd[k]);          // off by an ulp: cell-exit parameters move by 1e-7 of themselves, the slack is 2^-12 of the extent
+                    moving[k] = __builtin_fabsf(inv[k]) < inf;      // a zero (or denormal: v_rcp gives inf) component does not move the ray along this axis
+                    if (moving[k]) {
                         const float ta = (lo - oo[k]) * inv[k], tb = (hi - oo[k]) * inv[k];
                         t_in  = fmaxf(t_in, fminf(ta, tb));
                         t_out = fminf(t_out, fmaxf(ta, tb));
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     c = c < 0 ? 0 : (c >= (int)P.grid.dim[k] ? (int)P.grid.dim[k] - 1 : c);
                     cidx += (uint32_t)c * stride[k];
                     const bool fwd = dd[k] > 0.0f;
-                    if (dd[k] != 0.0f) {
+                    if (moving[k]) {
                         tn[k] = (P.grid.gmin[k] + (float)(c + (fwd ? 1 : 0)) * P.grid.h[k] - oo[k]) * inv[k];
                         dt[k] = P.grid.h[k] * __builtin_fabsf(inv[k]);
                         rem  |= (uint32_t)(fwd ? (int)P.grid.dim[k] - 1 - c : c) << (10 * k);
@@ -393,7 +396,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 // Registration tier of this ray: the lists that are valid up to the farthest point the walk can reach, i.e. the
                 // box's exit or the hit already found on the big list (the ground), whichever is nearer -- one decision per ray
                 // instead of one per cell (the outermost tier is valid wherever the origin passed the test above).
-                const float s_max = fminf(t_out, closest + slack_t) * (sqrtf(a) * 1.000001f);     // as a distance, rounded up
+                const float s_max = fminf(t_out, closest + slack_t) * (__builtin_amdgcn_sqrtf(a) * 1.00001f);     // as a distance, rounded up
                 const bool  tier1 = !(s_max <= P.grid.tier_s[0]), tier2 = !(s_max <= P.grid.tier_s[1]);   // NaN: the widest lists
                 uint32_t it = 0u, it_end = 0u;
                 bool     fresh_cell = true;

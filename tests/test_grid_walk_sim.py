@@ -65,10 +65,10 @@ def _walk(table, g, o, d):
     lo = gmin
     hi = (gmin + dim.astype(f32) * h).astype(f32)
     off = np.maximum(np.maximum(lo - o, o - hi), f32(0)).astype(f32)
-    l_far = f32(f32(np.sqrt(f32(off @ off))) * f32(1.000001) + g["box_diag"])
+    l_far = f32(f32(np.sqrt(f32(off @ off))) * f32(1.00001) + g["box_diag"])
     far = not (l_far <= g["tier_s"][2])
     rm = g["r_min"]
-    extra = f32(pad + (f32(np.sqrt(f32(rm * rm + f32(2.0 ** -19) * f32(l_far * l_far + rm * rm)))) * f32(1.000001) - rm)) if far else f32(0)
+    extra = f32(pad + (f32(np.sqrt(f32(rm * rm + f32(2.0 ** -19) * f32(l_far * l_far + rm * rm)))) * f32(1.00001) - rm)) if far else f32(0)
     t_in, t_out, walking = f32(0), f32(np.inf), True
     inv = np.zeros(3, f32)
     for k in range(3):
@@ -100,7 +100,7 @@ def _walk(table, g, o, d):
         else:
             tn[k] = f32(np.inf)
         cs[k] = stride[k] if fwd else -stride[k]
-    s_max = f32(min(t_out, f32(best[0] + slack_t)) * f32(f32(np.sqrt(a)) * f32(1.000001)))
+    s_max = f32(min(t_out, f32(best[0] + slack_t)) * f32(f32(np.sqrt(a)) * f32(1.00001)))
     tier = 2 if not (s_max <= g["tier_s"][1]) else (1 if not (s_max <= g["tier_s"][0]) else 0)
     start, tend, items = g["cell_start"], g["tier_end"], g["items"]
     while True:
