@@ -372,6 +372,12 @@ def test_grid_filter_reproduces_the_far_field_noise(ra, case):
             primary, st = ctx.render(cols, rows, 0, spp, 6, 11, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
             assert st["filter_misses"] == 0, (case, kind, st)
             out[kind] = (primary, ctx.read_accum(), st)
+        # the production kernel of the grid (no validation: another instantiation of the template) gives the same frame
+        ctx.set_filter(ra.FILTER_GRID)
+        primary, st = ctx.render(cols, rows, 0, spp, 6, 11, chunk_spp=spp, want_primary=True)
+        plain = ctx.read_accum()
+        same = (bits(plain) == bits(out[ra.FILTER_GRID][1])) | (np.isnan(plain) & np.isnan(out[ra.FILTER_GRID][1]))
+        assert (primary == out[ra.FILTER_GRID][0]).all() and same.all() and st["rays"] == out[ra.FILTER_GRID][2]["rays"]
     finally:
         ctx.close()
     (p_g, a_g, s_g), (p_v, a_v, s_v) = out[ra.FILTER_GRID], out[ra.FILTER_VALU]
