@@ -8,7 +8,8 @@ import raytracing_amd as ra
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-filt = {"grid": ra.FILTER_GRID, "mfma": ra.FILTER_MFMA, "valu": ra.FILTER_VALU}[sys.argv[3] if len(sys.argv) > 3 else "grid"]
+mode = sys.argv[3] if len(sys.argv) > 3 else "grid"      # "pair": the production kernels of grid and mfma against those of valu, frame by frame
+filt = {"grid": ra.FILTER_GRID, "mfma": ra.FILTER_MFMA, "valu": ra.FILTER_VALU, "pair": ra.FILTER_GRID}[mode]
 t0, runs, rays, misses = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     kind = rng.integers(0, 4)
@@ -46,7 +47,17 @@ while time.time() - t0 < budget:
         ctx.set_tuning("grid_density_pct", int(10 ** rng.uniform(0.7, 2.6)))
         ctx.upload_scene(t)
         ctx.set_camera(ra.Camera(fov, cols / rows, 0.0, 1.0, pos.astype(np.float32), (0, 1, 0), look.astype(np.float32)))
-        _, st = ctx.render(cols, rows, 0, 2, 8, int(rng.integers(1, 1 << 30)), flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=2)
+        seed = int(rng.integers(1, 1 << 30))
+        if mode == "pair":
+            frames = []
+            for f in (ra.FILTER_VALU, ra.FILTER_GRID, ra.FILTER_MFMA):
+                ctx.set_filter(f)
+                _, st = ctx.render(cols, rows, 0, 2, 8, seed, chunk_spp=2)
+                frames.append(ctx.read_accum().view(np.uint32))
+            nan = np.isnan(frames[0].view(np.float32))
+            st["filter_misses"] = int(((frames[1] != frames[0]) & ~nan).sum() + ((frames[2] != frames[0]) & ~nan).sum())
+        else:
+            _, st = ctx.render(cols, rows, 0, 2, 8, seed, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=2)
     finally:
         ctx.close()
     runs += 1; rays += st["rays"]; misses += st["filter_misses"]
