@@ -202,7 +202,7 @@ int rtx_resolve_rgbx8(rtx_ctx* ctx, uint32_t spp_total, uint32_t debug_tile, uin
  * samples rtx_spp_range(r, R, ...) of EVERY pixel into its own full-frame accumulation buffer; the Philox counter carries
  * the global sample index, so the union over members is exactly the one-GPU sample set and primary hits do not depend
  * on the device count.  rtx_group_allreduce is the one exchange: ncclAllReduce(sum, float32) of rows*cols*3 floats in
- * place.  Invariant: the SUM over the members' buffers is the image's colour sum -- after the exchange member 0 holds the
+ * place (RTX_GROUP_EXCHANGE=reduce in the environment: ncclReduce to member 0 instead).  Invariant: the SUM over the members' buffers is the image's colour sum -- after the exchange member 0 holds the
  * total and the others are zeroed, so RTX_FLAG_ACCUMULATE passes and further exchanges count every sample once.
  * A group of one device is rtx_render bit for bit (its exchange is the identity and RCCL is not initialised).
  * All calls block.  Members can be tuned individually through rtx_group_member.  Rehearsal on a one-GPU box: with
@@ -223,6 +223,14 @@ int rtx_group_set_camera(rtx_group* group, const rtx_camera* cam);
 int rtx_group_render(rtx_group* group, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
                      uint64_t seed, uint32_t flags, uint32_t chunk_spp, rtx_stats* stats);
 int rtx_group_allreduce(rtx_group* group);
+/* Milliseconds that member 0's part of the most recent exchange took (HIP events on member 0's stream around the RCCL group
+ * call; 0 for a group of one).  When the members were not synchronised beforehand it includes the wait for the slowest member. */
+int rtx_group_last_exchange_ms(rtx_group* group, double* ms);
+/* One whole frame pass without a host wait in between: rtx_group_render (no statistics) + rtx_group_allreduce +
+ * rtx_group_resolve_rgbx8(spp_total), each queued behind the other on the members' streams -- what the body of a multi-GPU
+ * renderScene (raytracer.cpp:60-143) amounts to; returns when framebuffer_host is filled. */
+int rtx_group_render_frame(rtx_group* group, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                           uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host);
 /* rtx_resolve_rgbx8 on member 0 (call rtx_group_allreduce first). */
 int rtx_group_resolve_rgbx8(rtx_group* group, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host);
 /* Contiguous share of [spp_begin, spp_begin + spp_count) of member `rank` of `world`; remainder samples go to the lowest

@@ -19,7 +19,7 @@ EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "r
            "rtx_render_noalloc", "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
            "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks", "rtx_build_grid",
            "rtx_version", "rtx_group_create", "rtx_group_destroy", "rtx_group_size", "rtx_group_member", "rtx_group_upload_scene", "rtx_group_set_camera",
-           "rtx_group_render", "rtx_group_allreduce", "rtx_group_resolve_rgbx8", "rtx_spp_range"]
+           "rtx_group_render", "rtx_group_allreduce", "rtx_group_last_exchange_ms", "rtx_group_render_frame", "rtx_group_resolve_rgbx8", "rtx_spp_range"]
 
 
 class RtxError(RuntimeError):
@@ -123,6 +123,8 @@ def lib():
     L.rtx_group_set_camera.argtypes = [C.c_void_p, P(CCamera)]
     L.rtx_group_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, P(Stats)]
     L.rtx_group_allreduce.argtypes = [C.c_void_p]
+    L.rtx_group_last_exchange_ms.argtypes = [C.c_void_p, P(C.c_double)]
+    L.rtx_group_render_frame.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, u32, u32, up]
     L.rtx_group_resolve_rgbx8.argtypes = [C.c_void_p, u32, u32, up]
     L.rtx_spp_range.restype = None
     L.rtx_spp_range.argtypes = [u32, u32, u32, u32, up, up]
@@ -430,6 +432,19 @@ class Group:
 
     def allreduce(self):
         _check(lib().rtx_group_allreduce(self._h))
+
+    def last_exchange_ms(self):
+        ms = C.c_double(0)
+        _check(lib().rtx_group_last_exchange_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def render_frame(self, cols, rows, spp_begin, spp_count, max_depth, seed, spp_total, flags=0, chunk_spp=0, debug_tile=0, out=None):
+        """rtx_group_render_frame: every member's share, the exchange and the resolve queued behind one another; returns the
+        8-bit framebuffer (written into `out` when given)."""
+        fb = out if out is not None else np.zeros(cols * rows, dtype=np.uint32)
+        _check(lib().rtx_group_render_frame(self._h, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, spp_total, debug_tile, _up(fb)))
+        self.cols, self.rows = cols, rows
+        return fb
 
     def resolve(self, spp_total, debug_tile=0):
         fb = np.zeros(self.cols * self.rows, dtype=np.uint32)

@@ -800,6 +800,8 @@ struct rtx_group {
     std::vector<rtx_ctx*>   members;
     std::vector<ncclComm_t> comms;        // empty for a group of one: its all-reduce is the identity
     bool                    loopback = false;   // RTX_GROUP_LOOPBACK=1: several members on ONE device, exchange without RCCL (rehearsal)
+    hipEvent_t              ex0 = nullptr, ex1 = nullptr;   // on member 0's stream, around its part of the most recent exchange
+    bool                    ex_timed = false;
 };
 
 // the exchange of a loopback group: dst += src (same device)
@@ -832,6 +834,9 @@ extern "C" int rtx_group_destroy(rtx_group* g)
         if (g->members[i]) (void)hipSetDevice(g->members[i]->device);
         if (g->comms[i]) (void)ncclCommDestroy(g->comms[i]);
     }
+    if (!g->members.empty() && g->members[0]) (void)hipSetDevice(g->members[0]->device);
+    if (g->ex0) (void)hipEventDestroy(g->ex0);
+    if (g->ex1) (void)hipEventDestroy(g->ex1);
     for (rtx_ctx* c : g->members) (void)rtx_destroy(c);
     delete g;
     return RTX_OK;
@@ -873,6 +878,10 @@ extern "C" int rtx_group_create(const int* device_ids, int n_devices, rtx_group*
             return fail(RTX_ERR_DEVICE, "rtx_group_create: ncclCommInitAll over %d devices failed: %s", n_devices, ncclGetErrorString(r));
         }
     }
+    if (hipSetDevice(g->members[0]->device) != hipSuccess || hipEventCreate(&g->ex0) != hipSuccess || hipEventCreate(&g->ex1) != hipSuccess) {
+        rtx_group_destroy(g);
+        return fail(RTX_ERR_DEVICE, "rtx_group_create: cannot create the exchange's events");
+    }
     *out = g;
     return RTX_OK;
 }
@@ -906,24 +915,24 @@ extern "C" int rtx_group_set_camera(rtx_group* g, const rtx_camera* cam)
     return RTX_OK;
 }
 
-extern "C" int rtx_group_render(rtx_group* g, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
-                                uint64_t seed, uint32_t flags, uint32_t chunk_spp, rtx_stats* stats)
+// Queues every member's share of the sample range on its own stream, device after device, and waits for nothing: the
+// launches of all devices run side by side.
+static int group_enqueue_render(rtx_group* g, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                                uint64_t seed, uint32_t flags, uint32_t chunk_spp, bool want_stats)
 {
-    if (!g) return fail(RTX_ERR_ARG, "rtx_group_render: group is NULL");
     if (cols == 0 || rows == 0 || spp_count == 0) return fail(RTX_ERR_ARG, "rtx_group_render: cols, rows and spp_count must be non-zero");
     const uint32_t world = (uint32_t)g->members.size();
-    // every member first: the launches of all devices run side by side
     for (uint32_t r = 0; r < world; ++r) {
         rtx_ctx* c = g->members[r];
         uint32_t begin = 0, count = 0;
         rtx_spp_range(r, world, spp_begin, spp_count, &begin, &count);
+        HIP_TRY(hipSetDevice(c->device));                        // every per-member call below runs with the member's device current
         if (c->ev_open) { double dummy; const int rc0 = rtx_last_kernel_ms(c, &dummy); if (rc0) return rc0; }
         if (count) {
-            const int rc = enqueue_render(c, cols, rows, begin, count, max_depth, seed, flags, chunk_spp, false, stats != nullptr);
+            const int rc = enqueue_render(c, cols, rows, begin, count, max_depth, seed, flags, chunk_spp, false, want_stats);
             if (rc) return rc;
         } else if (!(flags & RTX_FLAG_ACCUMULATE)) {
             // more devices than samples: this member contributes zeros (it still takes part in the all-reduce)
-            HIP_TRY(hipSetDevice(c->device));
             if (c->cols != cols || c->rows != rows) HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->accum_borrowed) {
                 if (c->accum_floats != (size_t)cols * rows * 3) return fail(RTX_ERR_STATE, "rtx_group_render: a member's borrowed accumulation buffer has the wrong size");
@@ -933,11 +942,21 @@ extern "C" int rtx_group_render(rtx_group* g, uint32_t cols, uint32_t rows, uint
             }
             c->cols = cols; c->rows = rows;
             HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)cols * rows * 3 * sizeof(float), c->stream));
-            if (stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
+            if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
         } else if (c->cols != cols || c->rows != rows || !c->accum) {
             return fail(RTX_ERR_STATE, "rtx_group_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
         }
     }
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_render(rtx_group* g, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                                uint64_t seed, uint32_t flags, uint32_t chunk_spp, rtx_stats* stats)
+{
+    if (!g) return fail(RTX_ERR_ARG, "rtx_group_render: group is NULL");
+    const uint32_t world = (uint32_t)g->members.size();
+    const int rc_q = group_enqueue_render(g, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, stats != nullptr);
+    if (rc_q) return rc_q;
     if (stats) memset(stats, 0, sizeof(*stats));
     for (uint32_t r = 0; r < world; ++r) {
         rtx_ctx* c = g->members[r];
@@ -964,51 +983,102 @@ extern "C" int rtx_group_render(rtx_group* g, uint32_t cols, uint32_t rows, uint
     return RTX_OK;
 }
 
-extern "C" int rtx_group_allreduce(rtx_group* g)
+// Queues the exchange behind every member's kernels and waits for nothing.  One collective: the sum of rows*cols*3 floats
+// (11.5 MB at 1200 x 800, 99.5 MB at 3840 x 2160), in place, each rank's part on that member's own stream.  It is an
+// all-reduce, as BASELINE's north star names it, although only member 0 needs the total: RCCL's all-reduce is the collective
+// it tunes for the fully connected xGMI node (a reduce to one root is a chain through the ranks), and at these sizes either is
+// a fraction of a millisecond.  RTX_GROUP_EXCHANGE=reduce (read per call) sends ncclReduce(root = member 0) instead -- half the
+// link traffic -- so that a multi-GPU run can time both (bench.py does, outside its timed region).
+static int group_enqueue_exchange(rtx_group* g)
 {
-    if (!g) return fail(RTX_ERR_ARG, "rtx_group_allreduce: group is NULL");
     const size_t world = g->members.size();
     rtx_ctx* c0 = g->members[0];
     if (!c0->accum || c0->cols == 0) return fail(RTX_ERR_STATE, "rtx_group_allreduce: nothing rendered yet");
     const size_t count = (size_t)c0->cols * c0->rows * 3;
     for (rtx_ctx* c : g->members)
         if (!c->accum || (size_t)c->cols * c->rows * 3 != count) return fail(RTX_ERR_STATE, "rtx_group_allreduce: the members hold images of different sizes");
+    g->ex_timed = false;
+    if (world == 1 && g->comms.empty()) return RTX_OK;          // a group of one: the sum over one buffer
+    HIP_TRY(hipSetDevice(c0->device));
     if (g->loopback) {
-        // member 0's buffer takes the others' in member order, behind everybody's kernels; then the invariant as below
-        HIP_TRY(hipSetDevice(c0->device));
-        for (rtx_ctx* c : g->members) HIP_TRY(hipStreamSynchronize(c->stream));
+        // member 0's buffer takes the others' in member order, behind everybody's kernels (the members share one device, so
+        // waiting for the other members' streams is the cross-stream dependency); then the invariant as below
+        for (size_t i = 1; i < world; ++i) HIP_TRY(hipStreamSynchronize(g->members[i]->stream));
+        HIP_TRY(hipEventRecord(g->ex0, c0->stream));
         for (size_t i = 1; i < world; ++i) {
             accum_add_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c0->stream>>>(c0->accum, g->members[i]->accum, count);
             HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipEventRecord(g->ex1, c0->stream));
+        g->ex_timed = true;
         HIP_TRY(hipStreamSynchronize(c0->stream));
         for (size_t i = 1; i < world; ++i) HIP_TRY(hipMemsetAsync(g->members[i]->accum, 0, count * sizeof(float), g->members[i]->stream));
-        for (rtx_ctx* c : g->members) HIP_TRY(hipStreamSynchronize(c->stream));
         return RTX_OK;
     }
-    if (g->comms.empty()) return RTX_OK;                         // a group of one: the sum over one buffer
-    // one collective: sum of rows*cols*3 floats (11.5 MB at 1200 x 800, 99.5 MB at 3840 x 2160), in place, each rank's part
-    // on that member's own stream, i.e. behind its trace and reduce kernels
+    const char* how = getenv("RTX_GROUP_EXCHANGE");
+    const bool  to_root = how && strcmp(how, "reduce") == 0;
+    HIP_TRY(hipEventRecord(g->ex0, c0->stream));
     NCCL_TRY(ncclGroupStart());
     for (size_t i = 0; i < world; ++i) {
         rtx_ctx* c = g->members[i];
-        const ncclResult_t r = ncclAllReduce(c->accum, c->accum, count, ncclFloat32, ncclSum, g->comms[i], c->stream);
-        if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(RTX_ERR_DEVICE, "ncclAllReduce on member %zu failed: %s", i, ncclGetErrorString(r)); }
+        const ncclResult_t r = to_root ? ncclReduce(c->accum, c->accum, count, ncclFloat32, ncclSum, 0, g->comms[i], c->stream)
+                                       : ncclAllReduce(c->accum, c->accum, count, ncclFloat32, ncclSum, g->comms[i], c->stream);
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(RTX_ERR_DEVICE, "the RCCL exchange on member %zu failed: %s", i, ncclGetErrorString(r)); }
     }
     NCCL_TRY(ncclGroupEnd());
-    // Invariant of a group: the SUM over the members' buffers is the image's colour sum.  After the exchange every member
-    // holds that total, so all but member 0 start again from zero -- a later RTX_FLAG_ACCUMULATE pass and the next
-    // exchange then count every sample once (progressive renders; multi_gpu.render_progressive keeps the same invariant).
+    HIP_TRY(hipSetDevice(c0->device));
+    HIP_TRY(hipEventRecord(g->ex1, c0->stream));
+    g->ex_timed = true;
+    // Invariant of a group: the SUM over the members' buffers is the image's colour sum.  After the exchange member 0 holds
+    // that total, so all the others start again from zero -- a later RTX_FLAG_ACCUMULATE pass and the next exchange then
+    // count every sample once (progressive renders; multi_gpu.render_progressive keeps the same invariant).
     for (size_t i = 1; i < world; ++i) {
         rtx_ctx* c = g->members[i];
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipMemsetAsync(c->accum, 0, count * sizeof(float), c->stream));
     }
+    return RTX_OK;
+}
+
+static int group_sync(rtx_group* g)
+{
     for (rtx_ctx* c : g->members) {
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return RTX_OK;
+}
+
+extern "C" int rtx_group_allreduce(rtx_group* g)
+{
+    if (!g) return fail(RTX_ERR_ARG, "rtx_group_allreduce: group is NULL");
+    const int rc = group_enqueue_exchange(g);
+    if (rc) return rc;
+    return group_sync(g);
+}
+
+extern "C" int rtx_group_last_exchange_ms(rtx_group* g, double* ms)
+{
+    if (!g || !ms) return fail(RTX_ERR_ARG, "rtx_group_last_exchange_ms: NULL argument");
+    *ms = 0.0;
+    if (!g->ex_timed) return RTX_OK;                             // a group of one, or no exchange yet
+    HIP_TRY(hipSetDevice(g->members[0]->device));
+    HIP_TRY(hipEventSynchronize(g->ex1));
+    float f = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&f, g->ex0, g->ex1));
+    *ms = f;
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_render_frame(rtx_group* g, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                                      uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host)
+{
+    if (!g || !framebuffer_host) return fail(RTX_ERR_ARG, "rtx_group_render_frame: NULL argument");
+    int rc = group_enqueue_render(g, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, false);
+    if (rc == RTX_OK) rc = group_enqueue_exchange(g);
+    if (rc == RTX_OK) rc = rtx_resolve_rgbx8(g->members[0], spp_total, debug_tile, framebuffer_host);    // waits for member 0's stream
+    if (rc) return rc;
+    return group_sync(g);                                        // the other members' zero fills
 }
 
 extern "C" int rtx_group_resolve_rgbx8(rtx_group* g, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host)

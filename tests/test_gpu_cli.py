@@ -111,17 +111,45 @@ def test_two_ranks_share_the_gpu_in_rehearsal(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     pa, pb = np.frombuffer(open(a, "rb").read()[-96 * 64 * 3:], dtype=np.uint8).astype(int), np.frombuffer(open(b, "rb").read()[-96 * 64 * 3:], dtype=np.uint8).astype(int)
     assert np.abs(pa - pb).max() <= 1 and (pa != pb).mean() < 0.01
-    r = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "8", "--cols", "160", "--rows", "100"],
+    # bench.py --gpus 2 under a launcher: strong scaling is the headline (the image's 9 samples split 5 + 4 over the ranks:
+    # BASELINE's 500 spp over 8 GPUs is timed this way), the weak figure (9 spp per rank) rides along
+    r = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "9", "--cols", "160", "--rows", "100"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "REHEARSAL" in line["config"]["parallelism"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "REHEARSAL" in line["config"]["parallelism"] and "9 spp in all" in line["config"]["workload"]
     assert line["value"] > 0 and "cpu_baseline" not in line and "other_workloads" not in line
-    weak_samples = line["value"] * line["ms_per_step"]
-    # --strong: the image's 9 samples split 5 + 4 over the ranks (BASELINE's 500 spp over 8 GPUs is timed this way)
-    r = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "9", "--cols", "160", "--rows", "100", "--strong"],
+    assert line["rccl_ranks"] == 2 and len(line["member_trace_ms"]) == 2 and line["exchange"]["allreduce_ms"] > 0
+    assert abs(line["value"] * line["ms_per_step"] / (160 * 100 * 9 / 1e3) - 1.0) < 1e-3
+    weak = line["weak_scaling"]
+    assert abs(weak["value"] * weak["ms_per_step"] / (160 * 100 * 18 / 1e3) - 1.0) < 1e-3
+    # --weak: the old headline
+    r = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "8", "--cols", "160", "--rows", "100", "--weak"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["scaling"] == "strong" and "9 spp in all" in line["config"]["workload"]
-    assert abs(line["value"] * line["ms_per_step"] / (160 * 100 * 9 / 1e3) - 1.0) < 1e-3 and abs(weak_samples / (160 * 100 * 16 / 1e3) - 1.0) < 1e-3
+    assert line["scaling"] == "weak" and "8 spp per GPU" in line["config"]["workload"] and "strong_scaling" in line
+    assert abs(line["value"] * line["ms_per_step"] / (160 * 100 * 16 / 1e3) - 1.0) < 1e-3
+
+
+def test_bench_drives_a_group_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher (WORLD_SIZE unset): ONE process drives the devices through rtx_group_* --
+    rehearsed here with two members on the one GPU (RTX_GROUP_LOOPBACK=1; the line says REHEARSAL).  Strong scaling is the
+    headline, the weak figure, the members' trace-kernel times and the exchange's own time ride along."""
+    import json
+    import sys
+    env = dict(os.environ, RTX_GROUP_LOOPBACK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RTX_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "9", "--cols", "160", "--rows", "100"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                                  # stdout carries the JSON line and nothing else
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "strong" and "REHEARSAL" in line["config"]["parallelism"]
+    assert "9 spp in all" in line["config"]["workload"] and len(line["member_trace_ms"]) == 2 and all(m > 0 for m in line["member_trace_ms"])
+    assert abs(line["value"] * line["ms_per_step"] / (160 * 100 * 9 / 1e3) - 1.0) < 1e-3
+    assert abs(line["weak_scaling"]["value"] * line["weak_scaling"]["ms_per_step"] / (160 * 100 * 18 / 1e3) - 1.0) < 1e-3
+    assert line["exchange"]["allreduce_ms"] > 0 and line["roofline"]["frac"] > 0
+    assert 2.0 < line["config"]["rays_per_sample"] < 3.5
