@@ -118,6 +118,12 @@ int rtx_set_filter(rtx_ctx* ctx, int kind);
  *   "wave_batch"     RTX_WAVE_BATCH      work items a wave reserves per trip to the counter; 0 = automatic
  *   "lds_pad"        RTX_LDS_PAD         extra LDS bytes per workgroup (experiments on occupancy)
  *   "grid_density_pct" RTX_GRID_DENSITY_PCT  RTX_FILTER_GRID: spheres per grid cell x 100 (35); takes effect at the next rtx_upload_scene
+ *   "order"          RTX_ORDER           1 (default): a launch of a frame the context has traced before (same scene, camera, size;
+ *                                        automatic chunks) hands its work out most expensive strip of 64 pixels first, by the
+ *                                        rays the strips took in the previous launch; 0: never
+ *   "order_chunks"   RTX_ORDER_CHUNKS    most sample chunks of such a launch (16)
+ *   "order_share_pct" RTX_ORDER_SHARE_PCT share of such a launch's expected duration that its longest work item may take (50)
+ *   "tail_guard"     RTX_TAIL_GUARD      the last tail_guard x resident lanes work items are reserved on demand, not ahead (4)
  *   "print_phases"   RTX_PRINT_PHASES    diagnostic builds only */
 int rtx_set_tuning(rtx_ctx* ctx, const char* key, int value);
 
@@ -144,6 +150,14 @@ int rtx_render(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, u
  * chunks first, small ones last) and starts[0 .. *n_chunks] their boundaries relative to spp_begin (`cap` entries are
  * available; 64 always suffice).  A CPU restatement summing in that same order reproduces an automatic launch bit for bit. */
 int rtx_last_chunk_plan(rtx_ctx* ctx, uint32_t* chunk_spp, uint32_t* n_chunks, uint32_t* starts, uint32_t cap);
+
+/* Whether the most recent rtx_render / rtx_render_async ran a cost-ordered work list (no counterpart in the reference, whose
+ * thread pool hands tiles out in image order, raytracer.cpp:93-127): the first launch of a frame (scene, camera, size) measures
+ * what every strip of 64 consecutive pixels costs -- the most rays one of its pixels took -- and later launches of that frame
+ * start the expensive strips first, so that what is still running when the work list is exhausted are the cheapest items of
+ * the frame.  Results never depend on the order (a pixel's samples are summed per chunk, the chunks in chunk order);
+ * rtx_last_chunk_plan reports the chunks either way. */
+int rtx_last_launch_ordered(rtx_ctx* ctx, int* ordered);
 
 /* rtx_render for callers that cannot allocate: it calls no hipMalloc / hipFree and no routine that allocates.  It has no
  * counterpart in the reference; it is for callers that must not allocate while they render -- code under HIP graph

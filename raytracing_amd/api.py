@@ -15,7 +15,7 @@ FLAG_ACCUMULATE, FLAG_RECURSIVE, FLAG_VALIDATE_FILTER = 1, 2, 4
 FILTER_VALU, FILTER_MFMA, FILTER_GRID, FILTER_AUTO = 0, 1, 2, 3
 
 # every symbol include/rtx.h declares
-EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_set_camera", "rtx_render",
+EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_last_launch_ordered", "rtx_set_camera", "rtx_render",
            "rtx_render_noalloc", "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
            "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks", "rtx_build_grid",
            "rtx_version", "rtx_group_create", "rtx_group_destroy", "rtx_group_size", "rtx_group_member", "rtx_group_upload_scene", "rtx_group_set_camera",
@@ -92,6 +92,7 @@ def lib():
     L.rtx_set_filter.argtypes = [C.c_void_p, C.c_int]
     L.rtx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.rtx_last_chunk_plan.argtypes = [C.c_void_p, up, up, up, u32]
+    L.rtx_last_launch_ordered.argtypes = [C.c_void_p, P(C.c_int)]
     L.rtx_set_camera.argtypes = [C.c_void_p, P(CCamera)]
     L.rtx_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32, up, P(Stats)]
     L.rtx_render_async.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u64, u32, u32]
@@ -299,6 +300,12 @@ class Context:
         starts = np.zeros(64, dtype=np.uint32)
         _check(lib().rtx_last_chunk_plan(self._h, C.byref(cs), C.byref(n), _up(starts), 64))
         return (cs.value, None) if cs.value else (0, starts[:n.value + 1].copy())
+
+    def last_launch_ordered(self):
+        """True when the most recent launch ran a cost-ordered work list (rtx_last_launch_ordered)."""
+        v = C.c_int(0)
+        _check(lib().rtx_last_launch_ordered(self._h, C.byref(v)))
+        return bool(v.value)
 
     def set_camera(self, cam):
         c = cam.c if isinstance(cam, Camera) else cam

@@ -2,7 +2,10 @@
 // live in trace_kernel.hip.  No CPU fallback exists: every entry point that renders needs a gfx950 device.
 #include "rtx_device.h"
 
+#include <cstring>
 #include <rccl/rccl.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -23,6 +26,9 @@ constexpr size_t kScratchPartialBytes = 64ull << 20;                         // 
 static __device__ __align__(256) unsigned char scratch[kScratchCounterBytes + kScratchPartialBytes];
 
 static thread_local std::string g_last_error;
+#ifdef RTX_WAVE_TIMES
+static unsigned long long* g_wave_times = nullptr;      // diagnostic build: 5 words per wave, one device, one context at a time
+#endif
 
 static int fail(int code, const char* fmt, ...)
 {
@@ -53,6 +59,18 @@ struct Tuning {
     int partials_mb = 1024;     // cap of the partial-sum scratch in MiB
     int print_phases = 0;
     int grid_density_pct = 35;  // RTX_FILTER_GRID: spheres per grid cell x 100, applied at the next rtx_upload_scene
+    int order = 1;              // cost-ordered work lists for frames the context has traced before (0: never)
+    int order_chunks = 16;      // most sample chunks of a cost-ordered launch
+    int order_share_pct = 50;   // share of the launch's expected duration that its single longest item may take, in per cent
+    int tail_guard = 4;         // reservations are made on demand (not ahead of time) within this many items per resident lane of the list's end
+};
+
+// What identifies "the same frame" for the pixel-cost map: scene, camera and image size.
+struct FrameKey {
+    uint64_t   scene_version = 0;
+    rtx_camera cam{};
+    uint32_t   cols = 0, rows = 0;
+    bool operator==(const FrameKey& o) const { return scene_version == o.scene_version && cols == o.cols && rows == o.rows && memcmp(&cam, &o.cam, sizeof(cam)) == 0; }
 };
 
 // Launch geometry of one (filter, scene) pair: worked out once per scene, not per launch.
@@ -101,6 +119,20 @@ struct rtx_ctx {
     uint32_t   last_tab[kMaxPlanChunks + 1] = { 0 };   // chunk boundaries of the most recent launch (rtx_last_chunk_plan)
     uint32_t   last_nchunks = 0, last_chunk_spp = 0;
     unsigned char* scratch = nullptr;                  // this device's copy of the static scratch array (rtx_render_noalloc)
+    // Strip costs and the work order derived from them (see order_for_launch / build_order_list): cost[s] = most rays that a pixel
+    // of strip s (pixels 64 s .. 64 s + 63) took in the most recent launch (reduce_kernel writes it); order = the launch's
+    // (strip, chunk) batches sorted by expected duration, descending.
+    uint64_t  scene_version = 0;
+    uint32_t* cost = nullptr;  size_t cost_items = 0;   FrameKey cost_key;  uint32_t cost_spp = 0;   // cost_spp = 0: no map
+    bool      cost_fresh = false;                      // cost_total has not been read back yet
+    double    cost_mean_rays = 0.0;                    // rays per sample of the frame the cost map describes
+    uint32_t* order = nullptr; size_t order_items = 0;  FrameKey order_key; uint32_t order_cost_spp = 0;   // 0: no list
+    uint32_t  order_tab[kMaxPlanChunks + 1] = { 0 };   uint32_t order_nchunks = 0;   // the chunk plan the list was built for
+    uint32_t* sort_vals = nullptr; size_t sort_vals_items = 0;
+    unsigned long long* sort_keys = nullptr; size_t sort_keys_items = 0;     // 2 x batches: keys in, keys out
+    void*     sort_tmp = nullptr;  size_t sort_tmp_bytes = 0;
+    unsigned long long* cost_total = nullptr;          // device: rays of the whole frame in the most recent launch (reduce_kernel)
+    bool      last_ordered = false;                    // the most recent launch ran a cost-ordered work list
 };
 
 extern "C" const char* rtx_last_error(void) { return g_last_error.c_str(); }
@@ -126,7 +158,8 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     static const struct { const char* env; const char* key; } kEnv[] = {
         { "RTX_BLOCK", "block" }, { "RTX_STREAM", "stream" }, { "RTX_LDS_PAD", "lds_pad" }, { "RTX_ITEMS_PER_LANE", "items_per_lane" },
         { "RTX_MAX_CHUNKS", "max_chunks" }, { "RTX_WAVE_BATCH", "wave_batch" }, { "RTX_TAIL_FACTOR", "tail_factor" },
-        { "RTX_PARTIALS_MB", "partials_mb" }, { "RTX_PRINT_PHASES", "print_phases" }, { "RTX_GRID_DENSITY_PCT", "grid_density_pct" } };
+        { "RTX_PARTIALS_MB", "partials_mb" }, { "RTX_PRINT_PHASES", "print_phases" }, { "RTX_GRID_DENSITY_PCT", "grid_density_pct" },
+        { "RTX_TAIL_GUARD", "tail_guard" }, { "RTX_ORDER", "order" }, { "RTX_ORDER_CHUNKS", "order_chunks" }, { "RTX_ORDER_SHARE_PCT", "order_share_pct" } };
     for (const auto& kv : kEnv)
         if (const char* v = getenv(kv.env)) (void)rtx_set_tuning(c, kv.key, atoi(v));     // out-of-range values are ignored, as before
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -136,6 +169,7 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
     if (e == hipSuccess) e = hipMalloc(&c->work_counter, 256);
     if (e == hipSuccess) e = hipMalloc(&c->stats, (kStCount + 12) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->cost_total, sizeof(unsigned long long));
     if (e == hipSuccess) {
         void* p = nullptr;
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));      // this device's copy (the device is current)
@@ -151,7 +185,8 @@ extern "C" int rtx_destroy(rtx_ctx* c)
     if (!c) return RTX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->grid_cells, c->grid_geom, c->grid_items, c->grid_big, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats };
+    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->grid_cells, c->grid_geom, c->grid_items, c->grid_big, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats,
+                     c->cost, c->order, c->sort_keys, c->sort_vals, c->sort_tmp, c->cost_total };
     for (void* b : bufs) if (b) (void)hipFree(b);
     hipEvent_t evs[] = { c->ev_first, c->ev_last, c->ev_t0, c->ev_t1 };
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -302,6 +337,7 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
         c->grid = G.desc;
     }
     c->n = n; c->n_pad = n_pad; c->n_pad_mfma = n_pad_mfma; c->have_scene = true;
+    c->scene_version++;                                             // pixel costs of the previous scene say nothing about this one
     c->plan[0].valid = c->plan[1].valid = c->plan[2].valid = false;
     c->mfma_ok = mfma_ok; c->mfma_scale = (float)sgm; c->mfma_omax = 30000.0 / sgm;
     return RTX_OK;
@@ -323,6 +359,10 @@ extern "C" int rtx_set_tuning(rtx_ctx* c, const char* key, int value)
     else if (k == "partials_mb")    { ok = value >= 1; if (ok) t.partials_mb = value; }
     else if (k == "print_phases")   { t.print_phases = value != 0; }
     else if (k == "grid_density_pct") { ok = value >= 1 && value <= 6400; if (ok) t.grid_density_pct = value; }
+    else if (k == "tail_guard")     { ok = value >= 0 && value <= 4096; if (ok) t.tail_guard = value; }
+    else if (k == "order")          { ok = value == 0 || value == 1; if (ok) t.order = value; }
+    else if (k == "order_chunks")   { ok = value >= 1 && value <= (int)kMaxPlanChunks; if (ok) t.order_chunks = value; }
+    else if (k == "order_share_pct") { ok = value >= 1 && value <= 400; if (ok) t.order_share_pct = value; }
     else return fail(RTX_ERR_ARG, "rtx_set_tuning: unknown knob '%s'", key);
     if (!ok) return fail(RTX_ERR_ARG, "rtx_set_tuning: value %d is out of range for '%s'", value, key);
     c->plan[0].valid = c->plan[1].valid = c->plan[2].valid = false;
@@ -406,6 +446,8 @@ struct RenderBuffers {
     unsigned long long* stats = nullptr;
     uint32_t* primary = nullptr;
     float4*   att_stack = nullptr; size_t att_stack_items = 0;
+    uint32_t* cost = nullptr;               // NULL or npix: rays per pixel of this launch (reduce_kernel)
+    unsigned long long* cost_total = nullptr;
 };
 
 // Everything of a render that is arithmetic on the host: argument checks, filter choice, launch geometry, chunk plan.
@@ -415,11 +457,14 @@ struct RenderSetup {
     LaunchPlan  lp;
     uint32_t    npix = 0, nchunks = 0, n_items = 0, grid = 0;
     bool        accumulate = false, validate = false, fill_only = false;
+    bool        ordered = false;        // the launch runs a cost-ordered batch list (P.order is set once the list exists)
     uint64_t    att_entries = 0;
 };
 
+// order_mean_rays > 0: the launch runs the context's cost-ordered work list (c->order), whose pixels took that many rays per
+// sample on average when their costs were measured.
 static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
-                        uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint64_t max_items, RenderSetup* out)
+                        uint64_t seed, uint32_t flags, uint32_t chunk_spp, uint64_t max_items, RenderSetup* out, double order_mean_rays = 0.0)
 {
     if (!c) return fail(RTX_ERR_ARG, "%s: ctx is NULL", who);
     if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "%s: upload a scene and a camera first", who);
@@ -456,7 +501,25 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
 
     TraceParams& P = R.P;
     uint32_t first_len;                      // size of the largest chunk: a wave's reservation is served lane by lane, one item after another
-    if (chunk_spp == 0) {
+    // Cost-ordered launch (order_mean_rays > 0: the frame's strip costs are known): the work list is the launch's (strip, chunk)
+    // batches, strip-major over the strips sorted by cost, most expensive first (build_order_list), so the launch ends on the
+    // cheapest items of the frame (sky: one ray per sample) and needs far fewer chunks than the geometric plan below, whose
+    // many small chunks exist for the tail alone.  What bounds the chunk size is the single most expensive item, which starts
+    // at time 0: max_depth rays per sample for the chunk's samples, one ray per wave iteration, against the launch's
+    // spp * npix * mean / lanes iterations per lane; it may take order_share_pct of that.  Launches too short for chunks of
+    // at least three samples stay unordered: one reservation per 64 items of one or two samples is a trip to the counter
+    // every few iterations for every wave (16 spp: 3.4 against 2.9 ms).
+    const double order_c_max = order_mean_rays > 0.0 ? std::floor(0.01 * c->tune.order_share_pct * ((double)spp_count * (double)npix * order_mean_rays / (double)lanes) / (double)std::max<uint32_t>(max_depth, 1u)) : 0.0;
+    if (chunk_spp == 0 && order_c_max >= 3.0) {
+        max_items = std::min<uint64_t>(max_items, (1ull << 31) - 1);
+        if (npix > max_items) return fail(RTX_ERR_ARG, "%s: %llu pixels need more than the %llu work items the partial-sum scratch holds", who, (unsigned long long)npix, (unsigned long long)max_items);
+        const double c_max = order_c_max;
+        const uint64_t allowed = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->tune.order_chunks, max_items / npix));
+        R.nchunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)std::ceil((double)spp_count / c_max), allowed), spp_count));
+        for (uint32_t k = 0; k <= R.nchunks; ++k) P.chunk_tab[k] = (uint32_t)((uint64_t)spp_count * k / R.nchunks);
+        first_len = P.chunk_tab[1];
+        R.ordered = true;         // (enqueue_render builds the list for this plan and sets P.order before the launch)
+    } else if (chunk_spp == 0) {
         max_items = std::min<uint64_t>(max_items, (1ull << 31) - 1);
         if (npix > max_items) return fail(RTX_ERR_ARG, "%s: %llu pixels need more than the %llu work items the partial-sum scratch holds", who, (unsigned long long)npix, (unsigned long long)max_items);
         R.nchunks = plan_chunks(spp_count, npix, lanes, (uint32_t)c->tune.items_per_lane, (uint32_t)c->tune.max_chunks, (uint32_t)c->tune.tail_factor, max_items, P.chunk_tab);
@@ -466,9 +529,10 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
         R.nchunks = (spp_count + chunk_spp - 1) / chunk_spp;
         first_len = chunk_spp;
     }
-    const uint64_t n_items64 = npix * R.nchunks;
+    const uint64_t n_items64 = (R.ordered ? (npix + 63) / 64 * 64 : npix) * R.nchunks;     // an ordered list is whole strips: its last one may reach past the image
+    if (R.ordered && (npix + 63) / 64 > (1ull << 22)) return fail(RTX_ERR_ARG, "%s: internal: too many strips for an ordered list", who);
     if (n_items64 >= (1ull << 31)) return fail(RTX_ERR_ARG, "%s: %llu work items; raise chunk_spp", who, (unsigned long long)n_items64);
-    if (n_items64 > max_items) return fail(RTX_ERR_ARG, "%s: %llu work items exceed the %llu that the partial-sum scratch holds; raise chunk_spp", who, (unsigned long long)n_items64, (unsigned long long)max_items);
+    if (npix * R.nchunks > max_items) return fail(RTX_ERR_ARG, "%s: %llu work items exceed the %llu that the partial-sum scratch holds; raise chunk_spp", who, (unsigned long long)n_items64, (unsigned long long)max_items);
     R.n_items = (uint32_t)n_items64;
     // Reservation size: every trip to the one global counter is a device-scope atomic on one address, and 4096 waves taking
     // 64 one-sample items at a time saturate it (200 spp as 1-sample items: 34.7 ms with 64-item reservations, 24.6 ms with
@@ -476,7 +540,9 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
     // Larger tables mean longer bounce iterations and fewer trips, so the target shrinks with the table.
     uint32_t wave_batch = kWaveBatch;
     const uint64_t target = 512ull * 512ull / std::max<uint32_t>(c->n_pad, 512u);
-    while (wave_batch < 512u && (uint64_t)wave_batch * 2u * first_len <= target) wave_batch *= 2u;
+    // (a cost-ordered list keeps 64: a larger reservation would hand several of the most expensive items, which lie next to
+    // each other at the head of the list, to the same lanes one after another; its items are never tiny -- at most 16 chunks)
+    while (!R.ordered && wave_batch < 512u && (uint64_t)wave_batch * 2u * first_len <= target) wave_batch *= 2u;
     if (c->tune.wave_batch) wave_batch = (uint32_t)c->tune.wave_batch;
     if ((uint64_t)R.n_items + (uint64_t)R.lp.max_grid * (R.lp.block / 64u) * 2u * wave_batch >= (1ull << 32)) return fail(RTX_ERR_ARG, "%s: work counter would overflow; raise chunk_spp", who);
 
@@ -484,6 +550,7 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
     P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.mfma_scale = c->mfma_scale; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
     P.cols = cols; P.rows = rows; P.npix = R.npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = R.nchunks;
     P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = R.n_items; P.wave_batch = wave_batch;
+    P.tail_guard = (uint32_t)std::min<uint64_t>((uint64_t)c->tune.tail_guard * lanes, 1ull << 30);
     if (flags & RTX_FLAG_RECURSIVE) R.att_entries = (uint64_t)std::max<uint32_t>(max_depth, 1u) * R.lp.max_grid * R.lp.block;
     const uint32_t blocks_needed = (uint32_t)((n_items64 + R.lp.block - 1) / R.lp.block);
     R.grid = std::max<uint32_t>(1, std::min<uint32_t>(R.lp.max_grid, blocks_needed));
@@ -506,15 +573,88 @@ static int launch_render(rtx_ctx* c, RenderSetup& R, const RenderBuffers& B, uin
     }
     TraceParams& P = R.P;
     P.partials = B.partials; P.primary = B.primary; P.work_counter = B.work_counter; P.stats = B.stats; P.att_stack = B.att_stack;
+#ifdef RTX_WAVE_TIMES
+    if (!g_wave_times) { HIP_TRY(hipMalloc(&g_wave_times, 9u * 65536u * 8u)); HIP_TRY(hipMemset(g_wave_times, 0, 9u * 65536u * 8u)); }
+    P.wave_times = g_wave_times;
+#endif
     HIP_TRY(hipMemsetAsync(B.work_counter, 0, 256, c->stream));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
     HIP_TRY(launch_trace(P, R.filter, R.lp.table_mode, R.validate, R.grid, R.lp.block, R.lp.lds_bytes, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     c->ev_trace = true;
-    launch_reduce(B.partials, B.accum, R.npix, R.nchunks, R.accumulate, c->stream);
+    if (B.cost) HIP_TRY(hipMemsetAsync(B.cost_total, 0, sizeof(unsigned long long), c->stream));
+    launch_reduce(B.partials, B.accum, B.cost, B.cost ? B.cost_total : nullptr, R.npix, R.nchunks, R.accumulate, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_last, c->stream));
+    return RTX_OK;
+}
+
+// The work order of a launch (replaces the role of thread_pool.cpp:344-382's "next free thread takes the next tile": dynamic
+// balance, but with the long work handed out first).  A launch of a frame the context has traced before -- same scene, camera
+// and size -- knows what every strip of 64 consecutive pixels cost then (the most rays one of its pixels took, reduce_kernel)
+// and runs its (strip, chunk) batches in the order of their expected duration, cost x samples of the chunk, longest first:
+// the classic longest-processing-time-first rule.  Results do not depend on the order: a pixel's samples are summed per chunk
+// and the chunks in chunk order whichever lane runs them.
+// order_for_launch: *mean_rays receives the frame's rays per sample when the launch can run ordered, 0 otherwise (first
+// launch of a frame, caller-chosen chunks, ordering switched off).
+static int order_for_launch(rtx_ctx* c, const FrameKey& key, uint32_t chunk_spp, double* mean_rays)
+{
+    *mean_rays = 0.0;
+    if (chunk_spp != 0) return RTX_OK;
+    const size_t npix = (size_t)key.cols * key.rows, nstrips = (npix + 63) / 64;
+    const bool have_cost = c->cost && c->cost_spp != 0 && c->cost_key == key && c->cost_items >= nstrips;
+    if (have_cost && c->cost_fresh) {
+        // the frame's rays per sample, once per cost map.  Waits for the launch that wrote it.
+        unsigned long long total = 0;
+        HIP_TRY(hipMemcpyAsync(&total, c->cost_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->cost_mean_rays = std::max(1.0, (double)total / ((double)npix * (double)c->cost_spp));
+        c->cost_fresh = false;
+    }
+    const bool have_order = c->order && c->order_cost_spp != 0 && c->order_key == key;
+    if (have_cost || have_order) *mean_rays = c->cost_mean_rays;
+    return RTX_OK;
+}
+
+// key[b] = cost of the batch's strip, val[b] = strip | chunk << 22, for b = strip * nchunks + chunk
+static __global__ void __launch_bounds__(256) order_fill_kernel(const uint32_t* __restrict__ cost, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                                 uint32_t nstrips, uint32_t nchunks)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nstrips * nchunks) return;
+    const uint32_t strip = b / nchunks, chunk = b - strip * nchunks;
+    keys[b] = cost[strip];                // the sort is stable: equal keys stay in (strip, chunk) order
+    vals[b] = strip | (chunk << 22);
+}
+
+// Sorts the launch's batches for the chunk plan in P (on the context's stream, behind the launch that measured the costs).
+static int build_order_list(rtx_ctx* c, const FrameKey& key, const TraceParams& P, uint32_t nchunks)
+{
+    const size_t npix = (size_t)key.cols * key.rows, nstrips = (npix + 63) / 64, nb = nstrips * nchunks;
+    const bool have_cost  = c->cost && c->cost_spp != 0 && c->cost_key == key && c->cost_items >= nstrips;
+    const bool have_order = c->order && c->order_cost_spp != 0 && c->order_key == key;
+    const bool same_plan  = have_order && c->order_nchunks == nchunks && memcmp(c->order_tab, P.chunk_tab, (nchunks + 1) * sizeof(uint32_t)) == 0;
+    if (same_plan && !(have_cost && c->cost_spp > c->order_cost_spp)) return RTX_OK;       // the list in hand is the best there is
+    if (!have_cost) return 1;                                       // (no costs to sort by: the caller falls back to an unordered launch)
+    int rc = ensure(&c->order, &c->order_items, nb);
+    if (rc == RTX_OK) rc = ensure(&c->sort_vals, &c->sort_vals_items, nb);
+    if (rc == RTX_OK) rc = ensure(&c->sort_keys, &c->sort_keys_items, 2 * nb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(order_fill_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, c->cost, c->sort_keys, c->sort_vals, (uint32_t)nstrips, nchunks);
+    HIP_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, c->sort_keys, c->sort_keys + nb, c->sort_vals, c->order, nb, 0u, 64u, c->stream));
+    if (tmp_bytes > c->sort_tmp_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->sort_tmp) (void)hipFree(c->sort_tmp);
+        c->sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+        if (hipMalloc(&c->sort_tmp, tmp_bytes) != hipSuccess) return fail(RTX_ERR_NOMEM, "device allocation of %zu bytes for the batch sort failed", tmp_bytes);
+        c->sort_tmp_bytes = tmp_bytes;
+    }
+    HIP_TRY(rocprim::radix_sort_pairs_desc(c->sort_tmp, tmp_bytes, c->sort_keys, c->sort_keys + nb, c->sort_vals, c->order, nb, 0u, 64u, c->stream));
+    c->order_key = key; c->order_cost_spp = c->cost_spp; c->order_nchunks = nchunks;
+    memcpy(c->order_tab, P.chunk_tab, sizeof(c->order_tab));
     return RTX_OK;
 }
 
@@ -524,8 +664,28 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     RenderSetup R;
     if (c) HIP_TRY(hipSetDevice(c->device));
     const uint64_t cap_items = c ? ((uint64_t)c->tune.partials_mb << 20) / sizeof(float4) : 0;
-    int rc = setup_render(c, "rtx_render", cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, cap_items, &R);
+    int rc;
+    double order_mean_rays = 0.0;
+    FrameKey key;
+    const bool ordering = c && c->tune.order != 0 && c->have_scene && c->have_camera && cols != 0 && rows != 0 && (uint64_t)cols * rows <= (1ull << 28);
+    if (ordering) {
+        key.scene_version = c->scene_version; key.cam = c->cam; key.cols = cols; key.rows = rows;
+        rc = order_for_launch(c, key, chunk_spp, &order_mean_rays);
+        if (rc) return rc;
+    }
+    rc = setup_render(c, "rtx_render", cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, cap_items, &R, order_mean_rays);
     if (rc) return rc;
+    if (R.ordered) {
+        rc = build_order_list(c, key, R.P, R.nchunks);
+        if (rc < 0) return rc;
+        if (rc > 0) {             // no list can be made for this plan: the unordered launch after all
+            R = RenderSetup();
+            rc = setup_render(c, "rtx_render", cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, cap_items, &R, 0.0);
+            if (rc) return rc;
+        } else {
+            R.P.order = c->order;                                   // (ensure() may have moved it)
+        }
+    }
     if (R.accumulate && (c->cols != cols || c->rows != rows || !c->accum)) return fail(RTX_ERR_STATE, "rtx_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
     if (c->cols != cols || c->rows != rows) { HIP_TRY(hipStreamSynchronize(c->stream)); }
     if (c->accum_borrowed) {
@@ -537,7 +697,15 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     c->cols = cols; c->rows = rows;
     RenderBuffers B;
     B.accum = c->accum; B.work_counter = c->work_counter; B.stats = want_stats ? c->stats : nullptr;
+    c->last_ordered = R.P.order != nullptr;
     if (!R.fill_only) {
+        if (ordering) {
+            // this launch measures the pixels' costs for the next one of the same frame
+            rc = ensure(&c->cost, &c->cost_items, ((size_t)R.npix + 63) / 64);
+            if (rc) return rc;
+            B.cost = c->cost; B.cost_total = c->cost_total;
+            c->cost_key = key; c->cost_spp = spp_count; c->cost_fresh = true;
+        }
         rc = ensure(&c->partials, &c->partials_items, (size_t)R.n_items);
         if (rc) return rc;
         B.partials = c->partials; B.partials_items = c->partials_items;
@@ -555,6 +723,27 @@ static int enqueue_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         }
     }
     return launch_render(c, R, B, spp_count);
+}
+
+extern "C" int rtx_last_launch_ordered(rtx_ctx* c, int* ordered)
+{
+    if (!c || !ordered) return fail(RTX_ERR_ARG, "rtx_last_launch_ordered: NULL argument");
+    *ordered = c->last_ordered ? 1 : 0;
+    return RTX_OK;
+}
+
+// Diagnostic (tools/ only, not declared in rtx.h): the strip costs of the most recent launch and the batch list in use.
+extern "C" int rtx_debug_order(rtx_ctx* c, uint32_t* cost_host, size_t cost_cap, uint32_t* order_host, size_t order_cap, size_t* n_cost, size_t* n_order)
+{
+    if (!c) return RTX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t nstrips = ((size_t)c->cost_key.cols * c->cost_key.rows + 63) / 64, nb = nstrips * c->order_nchunks;
+    if (n_cost) *n_cost = c->cost ? nstrips : 0;
+    if (n_order) *n_order = c->order && c->order_cost_spp ? nb : 0;
+    if (c->cost && cost_host && cost_cap >= nstrips) HIP_TRY(hipMemcpy(cost_host, c->cost, nstrips * 4, hipMemcpyDeviceToHost));
+    if (c->order && c->order_cost_spp && order_host && order_cap >= nb) HIP_TRY(hipMemcpy(order_host, c->order, nb * 4, hipMemcpyDeviceToHost));
+    return RTX_OK;
 }
 
 extern "C" int rtx_last_chunk_plan(rtx_ctx* c, uint32_t* chunk_spp, uint32_t* n_chunks, uint32_t* starts, uint32_t cap)
@@ -634,6 +823,37 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     double ms = 0.0;
     rc = rtx_last_kernel_ms(c, &ms);
     if (rc) return rc;
+#ifdef RTX_WAVE_TIMES
+    if (g_wave_times && getenv("RTX_PRINT_WAVES")) {
+        // diagnostic build: when do the waves run dry and end, relative to the first wave's start (100 MHz clock -> microseconds)
+        std::vector<unsigned long long> w(9u * 65536u);
+        HIP_TRY(hipMemcpy(w.data(), g_wave_times, w.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0, iters = 0, lanes = 0; size_t nw = 0;
+        for (size_t i = 0; i < 65536; ++i) if (w[5 * i + 2]) { t0 = std::min(t0, w[5 * i]); t1 = std::max(t1, w[5 * i + 2]); iters += w[5 * i + 3]; lanes += w[5 * i + 4]; nw++; }
+        std::vector<double> start, dry, end;
+        for (size_t i = 0; i < 65536; ++i) if (w[5 * i + 2]) { start.push_back((w[5 * i] - t0) * 0.01); dry.push_back(w[5 * i + 1] ? (w[5 * i + 1] - t0) * 0.01 : -1.0); end.push_back((w[5 * i + 2] - t0) * 0.01); }
+        auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(p * (v.size() - 1))]; };
+        fprintf(stderr, "waves %zu  span %.1f us  iterations/wave %.1f  tracing lanes/iteration %.1f\n", nw, (t1 - t0) * 0.01, (double)iters / nw, (double)lanes / iters);
+        fprintf(stderr, "  start us: p0 %.1f p50 %.1f p99 %.1f p100 %.1f\n", pct(start, 0), pct(start, .5), pct(start, .99), pct(start, 1));
+        fprintf(stderr, "  dry   us: p0 %.1f p1 %.1f p50 %.1f p99 %.1f p100 %.1f\n", pct(dry, 0), pct(dry, .01), pct(dry, .5), pct(dry, .99), pct(dry, 1));
+        fprintf(stderr, "  end   us: p0 %.1f p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f p100 %.1f\n", pct(end, 0), pct(end, .01), pct(end, .1), pct(end, .5), pct(end, .9), pct(end, .99), pct(end, 1));
+        // how many waves are still running at the end minus x
+        for (double back : { 2000.0, 1000.0, 500.0, 250.0, 100.0, 50.0 }) {
+            size_t alive = 0; for (double e : end) if (e > (t1 - t0) * 0.01 - back) alive++;
+            fprintf(stderr, "  waves still running %.0f us before the end: %zu\n", back, alive);
+        }
+        // the 12 waves that ended last: when, and the longest item among the last items of their lanes
+        std::vector<std::pair<double, size_t>> byend;
+        for (size_t i = 0; i < 65536; ++i) if (w[5 * i + 2]) byend.push_back({ (w[5 * i + 2] - t0) * 0.01, i });
+        std::sort(byend.begin(), byend.end());
+        for (size_t k = byend.size() > 12 ? byend.size() - 12 : 0; k < byend.size(); ++k) {
+            const size_t i = byend[k].second; const unsigned long long* x = &w[5u * 65536u + 4u * i];
+            fprintf(stderr, "  wave %5zu end %.1f us dry %.1f iters %llu | longest last item: started %.1f us, %llu rays, pixel %llu (x %llu y %llu), s_end %llu\n", i, byend[k].first, w[5 * i + 1] ? (w[5 * i + 1] - t0) * 0.01 : -1.0, w[5 * i + 3],
+                    (double)x[0] * 0.01 + (w[5 * i] - t0) * 0.01, x[1], x[2], x[2] % cols, x[2] / cols, x[3]);
+        }
+        HIP_TRY(hipMemset(g_wave_times, 0, w.size() * 8));
+    }
+#endif
     if (primary_hit_host) {
         if (max_depth == 0 && !(flags & RTX_FLAG_RECURSIVE)) memset(primary_hit_host, 0xFF, (size_t)cols * rows * spp_count * sizeof(uint32_t));
         else HIP_TRY(hipMemcpy(primary_hit_host, c->primary, (size_t)cols * rows * spp_count * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -69,17 +69,23 @@ struct TraceParams {
     uint32_t      max_depth, key0, key1, flags;
     uint32_t      n_items;
     uint32_t      wave_batch; // work items a wave reserves per trip to the global counter (host: about 512 samples' worth)
-    float4*       partials;   // n_items x (sum r, g, b, 0): item = chunk * npix + pixel
+    uint32_t      tail_guard; // the last tail_guard items of the list are reserved on demand instead of ahead of time
+    const uint32_t* order;    // NULL: item it = (chunk it / npix, pixel it % npix); else cost-ordered batches of 64 items: items 64 b .. 64 b + 63 are
+                              // chunk order[b] >> 22 of the pixels 64 s .. 64 s + 63 of strip s = order[b] & 0x3FFFFF
+    float4*       partials;   // n_items x (sum r, g, b, rays as uint bits): item = chunk * npix + pixel
     float4*       att_stack;  // RTX_FLAG_RECURSIVE only: max_depth x (grid * block) attenuations
     uint32_t*     primary;    // NULL or spp_count * npix
     uint32_t*     work_counter;
     unsigned long long* stats; // kStCount counters
+#ifdef RTX_WAVE_TIMES
+    unsigned long long* wave_times;   // diagnostic build: 5 words per wave
+#endif
 };
 
 hipError_t launch_trace(const TraceParams& p, int filter, int table_mode, bool validate, uint32_t grid, uint32_t block, size_t lds_bytes, hipStream_t stream);
 int  trace_occupancy(int filter, int table_mode, size_t lds_bytes, uint32_t block);
 size_t trace_lds_bytes(int filter, int table_mode, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block);
-void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream);
+void launch_reduce(const float4* partials, float* accum, uint32_t* cost, unsigned long long* cost_total, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream);
 void launch_fill(float* accum, uint32_t n_floats, float value, bool accumulate, hipStream_t stream);
 void launch_resolve(const float* accum, uint32_t* fb, uint32_t cols, uint32_t rows, uint32_t spp_total, uint32_t debug_tile, hipStream_t stream);
 

@@ -172,10 +172,27 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     if (lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
     uint32_t w_next = uniform(pf);
     uint32_t w_end  = w_next + P.wave_batch;
-    if (lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
+    // The next reservation is fetched ahead of time so that the counter's latency stays hidden -- except near the end of the
+    // list (the last P.tail_guard items): a wave hands a reserved item out only when one of ITS lanes falls free, so every
+    // item held in reserve there can end up waiting for a busy wave while other waves idle; the last reservations are
+    // therefore made on demand.
+    bool have_pf = w_end + P.tail_guard < P.n_items;
+    if (have_pf && lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
+    // Cost-ordered launches (P.order != NULL): the work list is a list of batches of 64 items = one STRIP of 64 consecutive
+    // pixels x one sample chunk, sorted by the host by expected duration, longest first (order[b] = strip | chunk << 22), and
+    // a reservation is one batch.  Which strip and chunk a batch is, is wave-uniform (scalar registers, one scalar load per
+    // batch); a lane's item is the batch's pixel base + its offset.
+    uint32_t cur_base = 0u, cur_chunk = 0u;
+    auto batch_info = [&](uint32_t start, uint32_t& base, uint32_t& chunk) {
+        const uint32_t e = start < P.n_items ? P.order[start >> 6] : 0xFFFFFFFFu;
+        chunk = e >> 22;
+        base  = e == 0xFFFFFFFFu ? 0xFFFFFFC0u : ((e & 0x3FFFFFu) << 6);    // past the end: no pixel of the batch is valid
+    };
+    if (P.order) batch_info(w_next, cur_base, cur_chunk);
 
     // per-lane path state
     uint32_t st = kNeedItem, item = 0, pix = 0, prow = 0, s_cur = 0, s_end = 0, bounce = 0;
+    uint32_t item_rays = 0;      // _sceneHit calls of the current item: the pixel's cost, stored beside its partial sum
     V3       o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1), acc = mk(0, 0, 0);
     // wave-level counters
     uint32_t c_samples = 0, c_miss = 0, c_absorb = 0, c_depth = 0, c_filter_miss = 0, c_cand = 0;
@@ -198,40 +215,85 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     uint64_t ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     uint64_t ph_last = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RTX_WAVE_TIMES
+    // diagnostic build: per wave (start, counter seen dry, end) on the chip-wide 100 MHz clock + iterations + lane-iterations spent tracing
+    const uint64_t wt_start = __builtin_amdgcn_s_memrealtime();
+    uint64_t wt_dry = 0, wt_iters = 0, wt_lanes = 0;
+    uint32_t wt_item_t0 = 0, wt_last_t0 = 0, wt_last_rays = 0, wt_last_pix = 0, wt_last_len = 0;     // the item that finished last in this wave
+#endif
     for (;;) {
+#ifdef RTX_WAVE_TIMES
+        if (wt_dry == 0 && w_next >= P.n_items) wt_dry = __builtin_amdgcn_s_memrealtime();
+        wt_iters++;
+#endif
         // ---- (A) lanes whose item is finished take the next one (persistent tile fetch) -------------------------
         uint64_t need = __ballot(st == kNeedItem);
         if (need) {
             uint32_t cnt = (uint32_t)__popcll(need), r = rank_in(need), avail = w_end - w_next;
-            uint32_t it;
-            if (cnt <= avail) {
-                it = w_next + r;
-                w_next += cnt;
+            uint32_t chunk = 0u, npx = 0xFFFFFFFFu;      // the lane's new item: (chunk, pixel); pixel >= npix: none
+            bool     dry = false;
+            if (P.order) {
+                // strip batches of 64: the lane's pixel is its batch's base + its offset in the batch
+                uint32_t base = cur_base, off = (w_next + 64u - w_end) + r;
+                chunk = cur_chunk;
+                if (cnt <= avail) {
+                    w_next += cnt;
+                } else {
+                    if (!have_pf && lane == 0) pf = atomicAdd(P.work_counter, 64u);
+                    const uint32_t nb = uniform(pf);
+                    uint32_t nbase, nchunk;
+                    batch_info(nb, nbase, nchunk);
+                    if (r >= avail) { base = nbase; chunk = nchunk; off = r - avail; }
+                    w_next = nb + (cnt - avail);
+                    w_end  = nb + 64u;
+                    cur_base = nbase; cur_chunk = nchunk;
+                    have_pf = w_end + P.tail_guard < P.n_items;
+                    if (have_pf && lane == 0) pf = atomicAdd(P.work_counter, 64u);
+                }
+                npx = base + off;
+                dry = base == 0xFFFFFFC0u;
             } else {
-                uint32_t nb = uniform(pf);
-                it     = (r < avail) ? (w_next + r) : (nb + (r - avail));
-                w_next = nb + (cnt - avail);
-                w_end  = nb + P.wave_batch;
-                if (lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
+                uint32_t it;
+                if (cnt <= avail) {
+                    it = w_next + r;
+                    w_next += cnt;
+                } else {
+                    if (!have_pf && lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
+                    uint32_t nb = uniform(pf);
+                    it     = (r < avail) ? (w_next + r) : (nb + (r - avail));
+                    w_next = nb + (cnt - avail);
+                    w_end  = nb + P.wave_batch;
+                    have_pf = w_end + P.tail_guard < P.n_items;
+                    if (have_pf && lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
+                }
+                if (it < P.n_items) {
+                    chunk = it / P.npix;
+                    npx   = it - chunk * P.npix;
+                } else {
+                    dry = true;
+                }
             }
             if (st == kNeedItem) {
-                if (it < P.n_items) {
-                    item           = it;
-                    uint32_t chunk = it / P.npix;
-                    pix            = it - chunk * P.npix;
+                if (dry) {
+                    st = kDead;
+                } else if (npx < P.npix) {                 // (the last strip of an ordered list may reach past the image: such a lane asks again)
+                    pix            = npx;
+                    item           = chunk * P.npix + pix;
+                    item_rays      = 0u;
                     prow           = pix / P.cols;                     // once per item, not per sample
                     if (P.chunk_spp) {                                    // uniform chunks (caller's choice)
                         s_cur          = P.spp_begin + chunk * P.chunk_spp;
                         uint32_t e     = s_cur + P.chunk_spp, lim = P.spp_begin + P.spp_count;
                         s_end          = e < lim ? e : lim;
-                    } else {                                              // the launch's chunk plan: large chunks first, small ones last
+                    } else {                                              // the launch's chunk plan
                         s_cur = P.spp_begin + ctab[chunk];
                         s_end = P.spp_begin + ctab[chunk + 1u];
                     }
                     acc            = mk(0, 0, 0);
                     st             = kNeedSample;
-                } else {
-                    st = kDead;
+#ifdef RTX_WAVE_TIMES
+                    wt_item_t0 = (uint32_t)(__builtin_amdgcn_s_memrealtime() - wt_start);
+#endif
                 }
             }
         }
@@ -294,6 +356,10 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             if (!tmask) break;      // every lane is kDead: the queue is drained and all paths have ended
         }
         c_rays += (uint64_t)__popcll(tmask);
+        item_rays += tracing ? 1u : 0u;
+#ifdef RTX_WAVE_TIMES
+        wt_lanes += (uint64_t)__popcll(tmask);
+#endif
 
         // ---- (C) _sceneHit: conservative filter over all spheres, exact re-test of the candidates ----------------
         const float a = dot(d, d);                                        // sphere.cpp:73
@@ -864,7 +930,10 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             acc = add(acc, thr);                                          // color += _color(...), raytracer.cpp:184
             s_cur++;
             if (s_cur == s_end) {
-                P.partials[item] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+#ifdef RTX_WAVE_TIMES
+                wt_last_t0 = wt_item_t0; wt_last_rays = item_rays; wt_last_pix = pix; wt_last_len = s_end;
+#endif
+                P.partials[item] = make_float4(acc.x, acc.y, acc.z, __uint_as_float(item_rays));
                 st = kNeedItem;
             } else {
                 st = kNeedSample;
@@ -874,6 +943,22 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         RTX_STAMP(7);
     }
 
+#ifdef RTX_WAVE_TIMES
+    if (P.wave_times && lane == 0) {
+        unsigned long long* w = P.wave_times + 5u * (blockIdx.x * (blockDim.x >> 6) + wave);
+        w[0] = wt_start; w[1] = wt_dry; w[2] = __builtin_amdgcn_s_memrealtime(); w[3] = wt_iters; w[4] = wt_lanes;
+    }
+    if (P.wave_times) {
+        // the lane whose item finished last (largest start + is the last to write): approximated by the lane with the latest finish = any lane
+        // whose record was written in the final iterations; take the lane with the most rays among those that finished an item after the wave saw the counter dry
+        unsigned long long* w = P.wave_times + 5u * 65536u + 4u * (blockIdx.x * (blockDim.x >> 6) + wave);
+        uint32_t best_r = wt_last_rays;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o_ = (uint32_t)__shfl_xor((int)best_r, off); best_r = o_ > best_r ? o_ : best_r; }
+        const uint64_t who = __ballot(wt_last_rays == best_r);
+        if (lane == (uint32_t)__builtin_ctzll(who)) { w[0] = wt_last_t0; w[1] = wt_last_rays; w[2] = wt_last_pix; w[3] = wt_last_len; }
+    }
+#endif
     // wave totals -> global statistics
     if (P.stats) {
         if (FILTER == kFilterGrid && lane_tests) atomicAdd(&P.stats[kStCandidates], (unsigned long long)lane_tests);
@@ -894,15 +979,33 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
 
 // ---------------------------------------------------------------------------------------------------------------
 // accum[p] (+)= sum over chunks, in chunk order, of partials[chunk * npix + p]
-__global__ void __launch_bounds__(256) reduce_kernel(const float4* __restrict__ partials, float* __restrict__ accum, uint32_t npix, uint32_t nchunks, int accumulate)
+// cost (optional): cost[s] receives the largest number of rays (_sceneHit calls) that a pixel of strip s -- pixels 64 s .. 64 s + 63,
+// one wave of this kernel -- took in this launch, *cost_total the rays of the whole frame
+__global__ void __launch_bounds__(256) reduce_kernel(const float4* __restrict__ partials, float* __restrict__ accum, uint32_t* __restrict__ cost, unsigned long long* __restrict__ cost_total, uint32_t npix, uint32_t nchunks, int accumulate)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
     V3 total = mk(0, 0, 0);
-    for (uint32_t k = 0; k < nchunks; ++k) {
-        float4 v = partials[(size_t)k * npix + p];
-        total    = add(total, mk(v.x, v.y, v.z));
+    uint32_t rays = 0u;
+    if (p < npix)
+        for (uint32_t k = 0; k < nchunks; ++k) {
+            float4 v = partials[(size_t)k * npix + p];
+            total    = add(total, mk(v.x, v.y, v.z));
+            rays    += __float_as_uint(v.w);
+        }
+    if (cost) {
+        uint32_t most = rays, sum = rays;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t om = (uint32_t)__shfl_xor((int)most, off), os = (uint32_t)__shfl_xor((int)sum, off);
+            most = om > most ? om : most;
+            sum += os;
+        }
+        if (lane_id() == 0u && (p & ~63u) < npix) {
+            cost[p >> 6] = most;
+            atomicAdd(cost_total, (unsigned long long)sum);
+        }
     }
+    if (p >= npix) return;
     if (accumulate) total = add(mk(accum[3 * (size_t)p], accum[3 * (size_t)p + 1], accum[3 * (size_t)p + 2]), total);
     accum[3 * (size_t)p + 0] = total.x;
     accum[3 * (size_t)p + 1] = total.y;
@@ -978,9 +1081,9 @@ hipError_t launch_trace(const TraceParams& p, int filter, int table_mode, bool v
     return hipLaunchKernel(fn, dim3(grid), dim3(block), args, lds_bytes, stream);
 }
 
-void launch_reduce(const float4* partials, float* accum, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream)
+void launch_reduce(const float4* partials, float* accum, uint32_t* cost, unsigned long long* cost_total, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reduce_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, partials, accum, npix, nchunks, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(reduce_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, partials, accum, cost, cost_total, npix, nchunks, accumulate ? 1 : 0);
 }
 
 void launch_fill(float* accum, uint32_t n_floats, float value, bool accumulate, hipStream_t stream)
