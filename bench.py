@@ -117,7 +117,7 @@ def measured_traffic():
 
 
 def other_workloads(ra, device, book1):
-    """Side measurements outside the timed region (one GPU, the faster of two launches after a warm-up, trace-kernel time from HIP events):
+    """Side measurements outside the timed region (one GPU, the last of three launches queued back to back, trace-kernel time from HIP events):
     BASELINE configuration 5 (20 164 spheres, 100 spp) with the linear list and with the uniform grid, the
     bench scene with the grid, and the share of the bench frame that one of 8 GPUs traces under strong scaling (62 of 500 spp).
     Informational: `value` above is configuration 2 with the linear list."""
@@ -129,11 +129,11 @@ def other_workloads(ra, device, book1):
                 ctx.set_filter(kind)
                 ctx.upload_scene(table)
                 ctx.set_camera(ra.book_camera(COLS, ROWS))
-                ctx.render(COLS, ROWS, 0, 2, DEPTH, SEED)
-                ms = 1e30
-                for _ in range(2):
-                    _, st = ctx.render(COLS, ROWS, 0, spp, DEPTH, SEED, want_stats=True)
-                    ms = min(ms, ctx.last_trace_ms())
+                _, st = ctx.render(COLS, ROWS, 0, spp, DEPTH, SEED, want_stats=True)     # counters; the frame's strip costs for the launches below
+                for _ in range(3):                       # queued back to back: the last one starts on a busy GPU, as in a render loop
+                    ctx.render_async(COLS, ROWS, 0, spp, DEPTH, SEED)
+                ctx.sync()
+                ms = ctx.last_trace_ms()
                 out.setdefault(name, {})[fname] = {"msamples_per_s": round(st["samples"] / ms / 1e3, 1), "kernel_ms": round(ms, 3),
                                                   "exact_tests_per_ray": round(st["candidates"] / max(1, st["rays"]), 2)}
             finally:

@@ -160,15 +160,17 @@ int rtx_last_chunk_plan(rtx_ctx* ctx, uint32_t* chunk_spp, uint32_t* n_chunks, u
 int rtx_last_launch_ordered(rtx_ctx* ctx, int* ordered);
 
 /* rtx_render for callers that cannot allocate: it calls no hipMalloc / hipFree and no routine that allocates.  It has no
- * counterpart in the reference; it is for callers that must not allocate while they render -- code under HIP graph
- * capture, tight serving loops, harnesses that forbid it.  Inputs are the scene and camera already uploaded to `ctx`; the
- * output is accum_dev, cols*rows*3 floats of the CALLER's device memory on the context's GPU (colour sums as for
- * rtx_render; RTX_FLAG_ACCUMULATE adds to what it holds).  The work counter and the partial sums live in a static device
- * array of 64 MiB + 256 bytes that every GPU the library runs on holds until the process ends: a launch may use at most
- * 4 194 304 work items (pixels x sample chunks; automatic plans shrink to fit, which lengthens the tail of large
- * frames), more pixels than that fail with RTX_ERR_ARG.  RTX_FLAG_RECURSIVE (needs a per-lane stack) is refused; no
- * primary-hit map, no statistics.  All calls on one GPU share that array: calls that overlap on a GPU -- from two
- * contexts or two threads -- race.  Blocks until the image is complete. */
+ * counterpart in the reference; it is for callers that must not allocate while they render -- tight serving loops, harnesses
+ * that forbid it, memory-accounted processes.  (It is NOT capturable into a HIP graph: it runs on the context's own stream,
+ * queries the pointer and blocks until the image is complete.)  Inputs are the scene and camera already uploaded to `ctx`; the
+ * output is accum_dev, cols*rows*3 floats of the CALLER's device memory on the context's GPU (colour sums as for rtx_render;
+ * RTX_FLAG_ACCUMULATE adds to what it holds; an allocation smaller than that is refused with RTX_ERR_ARG).  The work counter and
+ * the partial sums live in a static device array of 64 MiB + 256 bytes that every GPU the library runs on holds until the
+ * process ends: a launch may use at most 4 194 304 work items (pixels x sample chunks; automatic plans shrink to fit, which
+ * lengthens the tail of large frames), more pixels than that fail with RTX_ERR_ARG.  RTX_FLAG_RECURSIVE (needs a per-lane
+ * stack) is refused; no primary-hit map, no statistics, no cost-ordered work list.  All calls on one GPU share that array:
+ * calls that overlap on a GPU -- from two contexts or two threads -- would race, so the array's first word is an "in use" flag
+ * (a host-side atomic per device) and the second of two overlapping calls of one process fails with RTX_ERR_STATE instead. */
 int rtx_render_noalloc(rtx_ctx* ctx, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
                        uint64_t seed, uint32_t flags, uint32_t chunk_spp, float* accum_dev);
 

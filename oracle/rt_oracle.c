@@ -318,7 +318,7 @@ void ro_camera_init(ro_camera* cam, float vfov, float aspect, float aperture, fl
     cam->lensRadius = aperture / 2.0f;
 
     float theta      = vfov * pi / 180.0f;           /* RADIANS(), utils.h:71 */
-    float halfHeight = tanf(theta / 2);
+    float halfHeight = tanf(theta / 2);   /* camera.h:31 "(float)tan( theta / 2 )": float argument -> the float overload in C++; pinned by the reference-made camera KAT */
     float halfWidth  = aspect * halfHeight;
 
     cam->origin = pos;

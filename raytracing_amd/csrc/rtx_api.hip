@@ -8,6 +8,8 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -26,6 +28,9 @@ constexpr size_t kScratchPartialBytes = 64ull << 20;                         // 
 static __device__ __align__(256) unsigned char scratch[kScratchCounterBytes + kScratchPartialBytes];
 
 static thread_local std::string g_last_error;
+// rtx_render_noalloc: one flag per device, raised while a call of this process uses that device's scratch array
+constexpr int kMaxScratchDevices = 64;
+static std::atomic<bool> g_scratch_busy[kMaxScratchDevices];
 #ifdef RTX_WAVE_TIMES
 static unsigned long long* g_wave_times = nullptr;      // diagnostic build: 5 words per wave, one device, one context at a time
 #endif
@@ -154,14 +159,28 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
     c->device = device_id;
     c->num_cu = prop.multiProcessorCount;
     // the environment is read here and nowhere else; rtx_set_filter / rtx_set_tuning change the values afterwards
-    if (const char* f = getenv("RTX_FILTER")) c->filter = (strcmp(f, "valu") == 0) ? kFilterValu : (strcmp(f, "grid") == 0 ? kFilterGrid : (strcmp(f, "auto") == 0 ? kFilterAuto : kFilterMfma));
+    if (const char* f = getenv("RTX_FILTER")) {
+        if (strcmp(f, "valu") == 0) c->filter = kFilterValu;
+        else if (strcmp(f, "mfma") == 0) c->filter = kFilterMfma;
+        else if (strcmp(f, "grid") == 0) c->filter = kFilterGrid;
+        else if (strcmp(f, "auto") == 0) c->filter = kFilterAuto;
+        else { delete c; return fail(RTX_ERR_ARG, "rtx_create: environment variable RTX_FILTER=%s is refused (valu, mfma, grid or auto)", f); }
+    }
     static const struct { const char* env; const char* key; } kEnv[] = {
         { "RTX_BLOCK", "block" }, { "RTX_STREAM", "stream" }, { "RTX_LDS_PAD", "lds_pad" }, { "RTX_ITEMS_PER_LANE", "items_per_lane" },
         { "RTX_MAX_CHUNKS", "max_chunks" }, { "RTX_WAVE_BATCH", "wave_batch" }, { "RTX_TAIL_FACTOR", "tail_factor" },
         { "RTX_PARTIALS_MB", "partials_mb" }, { "RTX_PRINT_PHASES", "print_phases" }, { "RTX_GRID_DENSITY_PCT", "grid_density_pct" },
         { "RTX_TAIL_GUARD", "tail_guard" }, { "RTX_ORDER", "order" }, { "RTX_ORDER_CHUNKS", "order_chunks" }, { "RTX_ORDER_SHARE_PCT", "order_share_pct" } };
     for (const auto& kv : kEnv)
-        if (const char* v = getenv(kv.env)) (void)rtx_set_tuning(c, kv.key, atoi(v));     // out-of-range values are ignored, as before
+        if (const char* v = getenv(kv.env)) {
+            char* end = nullptr;
+            const long val = strtol(v, &end, 10);
+            if (end == v || *end != '\0' || val < INT32_MIN || val > INT32_MAX || rtx_set_tuning(c, kv.key, (int)val) != RTX_OK) {
+                const std::string why = (end == v || *end != '\0') ? std::string("not an integer") : g_last_error;
+                delete c;
+                return fail(RTX_ERR_ARG, "rtx_create: environment variable %s=%s is refused (%s)", kv.env, v, why.c_str());
+            }
+        }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_first);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_last);
@@ -887,6 +906,7 @@ extern "C" int rtx_render_noalloc(rtx_ctx* c, uint32_t cols, uint32_t rows, uint
     if (!c || !accum_dev) return fail(RTX_ERR_ARG, "rtx_render_noalloc: NULL argument");
     if (flags & RTX_FLAG_RECURSIVE) return fail(RTX_ERR_ARG, "rtx_render_noalloc: RTX_FLAG_RECURSIVE needs a per-lane attenuation stack, which this entry point has no memory for; use rtx_render");
     if (!c->scratch) return fail(RTX_ERR_STATE, "rtx_render_noalloc: the context has no scratch address");
+    if (c->device < 0 || c->device >= kMaxScratchDevices) return fail(RTX_ERR_STATE, "rtx_render_noalloc: device %d is beyond the %d devices the scratch bookkeeping covers", c->device, kMaxScratchDevices);
     HIP_TRY(hipSetDevice(c->device));
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, accum_dev) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != c->device)
@@ -894,14 +914,32 @@ extern "C" int rtx_render_noalloc(rtx_ctx* c, uint32_t cols, uint32_t rows, uint
     RenderSetup R;
     int rc = setup_render(c, "rtx_render_noalloc", cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, kScratchPartialBytes / sizeof(float4), &R);
     if (rc) return rc;
+    // the allocation behind accum_dev must hold the whole image from accum_dev on (a query, not an allocation)
+    if (cols != 0 && rows != 0) {
+        hipDeviceptr_t base = nullptr;
+        size_t         size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)accum_dev) == hipSuccess) {
+            const size_t room = size - (size_t)((const char*)accum_dev - (const char*)base), want = (size_t)cols * rows * 3 * sizeof(float);
+            if (room < want) return fail(RTX_ERR_ARG, "rtx_render_noalloc: accum_dev has room for %zu bytes, a %u x %u image needs %zu", room, cols, rows, want);
+        } else {
+            (void)hipGetLastError();                  // sub-allocators may hand out pointers the runtime cannot size: type and device were checked above
+        }
+    }
+    // one launch at a time per GPU: the scratch array is shared by every context of the process on that device
+    bool expected = false;
+    if (!g_scratch_busy[c->device].compare_exchange_strong(expected, true, std::memory_order_acquire))
+        return fail(RTX_ERR_STATE, "rtx_render_noalloc: another rtx_render_noalloc is running on GPU %d (its calls share one scratch array and must not overlap)", c->device);
     RenderBuffers B;
     B.accum          = accum_dev;
     B.work_counter   = reinterpret_cast<uint32_t*>(c->scratch);
     B.partials       = reinterpret_cast<float4*>(c->scratch + kScratchCounterBytes);
     B.partials_items = kScratchPartialBytes / sizeof(float4);
     rc = launch_render(c, R, B, spp_count);
+    const hipError_t e = hipStreamSynchronize(c->stream);      // also after a failed enqueue: nothing of this call may still be running when the flag falls
+    g_scratch_busy[c->device].store(false, std::memory_order_release);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, "rtx_render_noalloc: %s", hipGetErrorString(e));
+    c->last_ordered = false;
     return RTX_OK;
 }
 

@@ -299,7 +299,9 @@ extern "C" int rtx_camera_init(rtx_camera* cam, float vfov, float aspect, float 
     const float pi = 3.14159265358979323846f;                 // utils.h:70, a float literal
     cam->lens_radius = aperture / 2.0f;                       // camera.h:28
     float theta      = vfov * pi / 180.0f;                    // camera.h:30
-    float halfHeight = tanf(theta / 2);                       // camera.h:31
+    float halfHeight = tanf(theta / 2);                       // camera.h:31 writes "(float)tan( theta / 2 )" with a float argument: in C++ with <cmath> in scope that is the float
+                                                              // overload, i.e. tanf -- which is what the reference's own object code computes: the camera KAT made by the compiled
+                                                              // reference (tests/golden, test_camera_matches_reference_constructor) fails with the double tan (tried in r3)
     float halfWidth  = aspect * halfHeight;
     H3 origin = h3(pos[0], pos[1], pos[2]);
     H3 w = unit(origin - h3(lookat[0], lookat[1], lookat[2])); // camera.h:35-37

@@ -77,6 +77,7 @@ int main(int argc, char** argv)
     if (args.cmdOptionExists("-G")) gpus = std::stoi(args.getCmdOption("-G"));
     if (args.cmdOptionExists("-D")) device = std::stoi(args.getCmdOption("-D"));
     if (gpus < 1 || device < 0) { printf("Error: -G needs a positive GPU count and -D a device index.\n"); return -1; }
+    if (args.cmdOptionExists("-G") && !args.cmdOptionExists("-D")) printf("note: -G %d is a GPU COUNT (devices 0 .. %d); -D <index> chooses the first device.\n", gpus, gpus - 1);
     unsigned passSpp = 0;
     if (args.cmdOptionExists("-p")) passSpp = (unsigned)std::stoi(args.getCmdOption("-p"));
     std::string checkpoint;
@@ -100,13 +101,17 @@ int main(int argc, char** argv)
     fclose(probe);
 
     rtx_stats st{};
-    struct PassCtx { std::string file; unsigned cols, rows, total; bool binary; } pc{ filename, cols, rows, (unsigned)aaSamples, binary };
+    static rtx_stats tot{};                 // all passes (opt.stats holds the last pass only)
+    static unsigned  tot_passes = 0;
+    struct PassCtx { std::string file; unsigned cols, rows, total; bool binary, write; const rtx_stats* last; } pc{ filename, cols, rows, (unsigned)aaSamples, binary, passSpp != 0, &st };
     HipRenderOptions opt;
     opt.seed = seed; opt.device = device; opt.n_devices = gpus; opt.stats = &st; opt.pass_spp = passSpp; opt.resume = resume; opt.filter = filter;
     opt.checkpoint = checkpoint.empty() ? nullptr : checkpoint.c_str();
     opt.user = &pc;
-    if (passSpp) opt.on_pass = [](const uint32_t* fb, unsigned done, void* user) -> bool {
+    opt.on_pass = [](const uint32_t* fb, unsigned done, void* user) -> bool {
         const PassCtx* p = (const PassCtx*)user;
+        tot.samples += p->last->samples; tot.rays += p->last->rays; tot.kernel_ms += p->last->kernel_ms; tot_passes++;
+        if (!p->write) return true;             // one-shot render: main() writes the file
         printf("pass done: %u of %u samples\n", done, p->total);
         fflush(stdout);
         return (p->binary ? rtx_write_ppm_p6(p->file.c_str(), p->cols, p->rows, fb) : rtx_write_ppm(p->file.c_str(), p->cols, p->rows, fb)) == 0;
@@ -116,9 +121,16 @@ int main(int argc, char** argv)
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != 0) { delete scene; return -1; }
     printf("renderSceneHIP: %f s (%zu spheres, %u x %u, %d spp, depth %d)\n", sec, scene->objects.size(), cols, rows, aaSamples, maxBounce);
-    if (st.kernel_ms > 0.0)      // no pass ran (-R on a finished checkpoint): there is nothing to report
-        printf("{\"msamples_per_s\": %.3f, \"mrays_per_s\": %.3f, \"kernel_ms\": %.3f, \"rays\": %llu, \"samples\": %llu}\n",
-               st.samples / (st.kernel_ms * 1e3), st.rays / (st.kernel_ms * 1e3), st.kernel_ms, (unsigned long long)st.rays, (unsigned long long)st.samples);
+    if (st.kernel_ms > 0.0) {    // (no pass ran -- -R on a finished checkpoint -- : there is nothing to report)
+        // one machine-readable line: whole-job figures over all passes and GPUs; kernel_ms sums, pass by pass, the
+        // slowest GPU's trace + reduce kernels.  mfma_frac: f16 matrix-core flop the linear list's filter issued (64 per ray and
+        // sphere of the table padded to 128) against the dense f16 peak of the GPUs used; 0 when another candidate search ran.
+        const size_t n_pad = (scene->objects.size() + 127) / 128 * 128;
+        const bool   linear = filter == RTX_FILTER_MFMA || (filter == -1 && !getenv("RTX_FILTER")) || (filter == RTX_FILTER_AUTO && scene->objects.size() < 257);
+        const double mfma_frac = linear ? 64.0 * (double)tot.rays * (double)n_pad / (tot.kernel_ms * 1e-3) / (2.5e15 * gpus) : 0.0;
+        printf("{\"msamples_per_s\": %.3f, \"mrays_per_s\": %.3f, \"kernel_ms\": %.3f, \"rays\": %llu, \"samples\": %llu, \"n_gpus\": %d, \"passes\": %u, \"mfma_frac_of_f16_peak\": %.4f, \"wall_s\": %.3f}\n",
+               tot.samples / (tot.kernel_ms * 1e3), tot.rays / (tot.kernel_ms * 1e3), tot.kernel_ms, (unsigned long long)tot.rays, (unsigned long long)tot.samples, gpus, tot_passes, mfma_frac, sec);
+    }
     rc = binary ? rtx_write_ppm_p6(filename.c_str(), cols, rows, frameBuffer.data()) : rtx_write_ppm(filename.c_str(), cols, rows, frameBuffer.data());
     delete scene;
     return rc == 0 ? 0 : -1;

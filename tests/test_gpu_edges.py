@@ -328,3 +328,18 @@ def test_automatic_chunk_plan_is_bit_exact_against_the_oracle(ra, ctx, oracle, g
         ctx.set_tuning("no_such_knob", 1)
     with pytest.raises(ra.RtxError):
         ctx.set_tuning("block", 100)
+
+
+def test_a_bad_environment_value_is_reported_not_swallowed():
+    """RTX_* variables are read once, at rtx_create: a value that rtx_set_tuning would refuse makes the create fail with a message
+    naming the variable (round 2 ignored it silently)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = "import raytracing_amd as ra\ntry:\n    ra.Context(0)\nexcept ra.RtxError as e:\n    print('REFUSED', e)\n"
+    for var, val in (("RTX_BLOCK", "100"), ("RTX_TAIL_FACTOR", "0"), ("RTX_MAX_CHUNKS", "many"), ("RTX_FILTER", "bvh")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, **{var: val}))
+        assert r.returncode == 0 and "REFUSED" in r.stdout and var in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code + "print('OK')"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, RTX_BLOCK="256", RTX_FILTER="grid"))
+    assert r.returncode == 0 and "REFUSED" not in r.stdout and "OK" in r.stdout, r.stdout + r.stderr

@@ -21,3 +21,20 @@ def test_host_code_under_asan_and_ubsan(tmp_path):
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "host fuzz ok" in r.stdout, (r.stdout + r.stderr)[-4000:]
+
+
+def test_oracle_tile_pool_under_thread_sanitizer(tmp_path):
+    """SURVEY s5 "race detection": the one threaded piece of host code in the repository -- the oracle's tile pool, which plays
+    the role of the reference's thread_pool.cpp workers -- built with -fsanitize=thread and run on 2, 5 and 8 threads; the frames
+    must equal the one-thread frame and ThreadSanitizer must stay silent."""
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "oracle_tsan"
+    src = [os.path.join(ROOT, "tests", "native", "oracle_tsan.c"), os.path.join(ROOT, "oracle", "rt_oracle.c")]
+    r = subprocess.run(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off", "-o", str(exe)] + src + ["-lm", "-lpthread"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
+    if r.returncode != 0 and "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
+    assert r.returncode == 0 and "oracle tsan ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-4000:]

@@ -20,7 +20,14 @@ def _hip():
     h.hipFree.argtypes = [C.c_void_p]
     h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    h.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     return h
+
+
+def _free_bytes(hip):
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
 
 
 class DeviceBuffer:
@@ -91,6 +98,58 @@ def test_noalloc_matches_rtx_render_twice_in_a_row_then_accumulates(golden_scene
     assert chunk_spp == 0 and len(starts) - 1 <= 4 and starts[-1] == 12
     ctx.render(1200, 800, 0, 12, 50, seed, want_stats=False)
     np.testing.assert_allclose(big.read(), ctx.read_accum(), rtol=1e-5, atol=1e-5)        # same samples, another chunk plan
-    for b in bufs + [big]:
+    # the property the entry point exists for: a call allocates nothing -- the device's free memory is the same before and
+    # after, also for a frame size and a plan this context has not rendered before (rtx_render would grow its buffers here)
+    odd = DeviceBuffer(hip, 640 * 360 * 3)
+    ctx.set_camera(ra.book_camera(640, 360))
+    before = _free_bytes(hip)
+    ctx.render_noalloc(640, 360, 0, 9, 50, seed, odd.ptr.value)
+    ctx.render_noalloc(1200, 800, 0, 5, 50, seed, big.ptr.value, chunk_spp=2)
+    assert _free_bytes(hip) == before
+    # a buffer too small for the image is refused, not overrun
+    with pytest.raises(ra.RtxError, match="room"):
+        ctx.render_noalloc(1200, 800, 0, 1, 50, seed, odd.ptr.value)
+    for b in bufs + [big, odd]:
         b.free()
     ctx.close()
+
+
+def test_overlapping_noalloc_calls_on_one_gpu_are_refused(golden_scenes):
+    """Every call on a GPU shares that GPU's scratch array: two calls that overlap -- two contexts, two threads -- would race, so
+    the second is refused with RTX_ERR_STATE while the first runs (and succeeds once it has ended)."""
+    import threading
+    import raytracing_amd as ra
+    hip = _hip()
+    cols, rows, spp = 1200, 800, 150                       # about 20 ms per call
+    ctxs, bufs = [], []
+    for _ in range(2):
+        c = ra.Context(0)
+        c.upload_scene(golden_scenes["book1"])
+        c.set_camera(ra.book_camera(cols, rows))
+        ctxs.append(c)
+        bufs.append(DeviceBuffer(hip, cols * rows * 3))
+    ctxs[0].render_noalloc(cols, rows, 0, 2, 50, 1, bufs[0].ptr.value)          # warm both up, one after the other
+    ctxs[1].render_noalloc(cols, rows, 0, 2, 50, 1, bufs[1].ptr.value)
+    gate, errors = threading.Barrier(2), [None, None]
+
+    def work(k):
+        gate.wait()
+        try:
+            ctxs[k].render_noalloc(cols, rows, 0, spp, 50, 1, bufs[k].ptr.value)
+        except ra.RtxError as e:
+            errors[k] = str(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    refused = [e for e in errors if e is not None]
+    assert len(refused) == 1 and "another rtx_render_noalloc" in refused[0] and "-3" in refused[0], errors
+    winner = errors.index(None)
+    ctxs[winner].render(cols, rows, 0, spp, 50, 1, want_stats=False)
+    np.testing.assert_allclose(bufs[winner].read(), ctxs[winner].read_accum(), rtol=1e-5, atol=1e-5)
+    ctxs[1 - winner].render_noalloc(cols, rows, 0, 3, 50, 1, bufs[1 - winner].ptr.value)      # the refused context works again afterwards
+    for c, b in zip(ctxs, bufs):
+        b.free()
+        c.close()
