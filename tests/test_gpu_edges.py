@@ -343,3 +343,33 @@ def test_a_bad_environment_value_is_reported_not_swallowed():
         assert r.returncode == 0 and "REFUSED" in r.stdout and var in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, "-c", code + "print('OK')"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, RTX_BLOCK="256", RTX_FILTER="grid"))
     assert r.returncode == 0 and "REFUSED" not in r.stdout and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_config3_at_its_own_sample_count(ra, ctx, golden_scenes):
+    """BASELINE configuration 3 on one GPU at full size: 3840x2160, 4096 spp, depth 50 in ONE launch (about 4 s; its 2 / 4 / 8-GPU
+    split traces the same samples, 2048 / 1024 / 512 per rank).  Counters add up, the partial sums stay under the 1 GiB cap, and
+    the 8-bit image equals the image of two accumulated 2048-sample launches -- the split a two-GPU group makes -- within one
+    level (the float sums are added in another order)."""
+    cols, rows, spp = 3840, 2160, 4096
+    npix = cols * rows
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(cols, rows))
+    _, st = ctx.render(cols, rows, 0, spp, 50, 1)
+    chunk_spp, starts = ctx.last_chunk_plan()
+    assert chunk_spp == 0 and starts[-1] == spp and (len(starts) - 1) * npix * 16 <= 1 << 30
+    assert st["samples"] == npix * spp and st["sphere_tests"] == st["rays"] * 485
+    assert st["term_miss"] + st["term_absorb"] + st["term_depth"] == st["samples"]
+    assert 2.6 < st["rays"] / st["samples"] < 2.8
+    assert st["samples"] / st["kernel_ms"] / 1e3 > 6000.0                # Msamples/s: no tail, no fallback (8 400 measured)
+    whole = ctx.read_accum()
+    fb_whole = ctx.resolve(spp)
+    assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() <= spp
+    _, st_a = ctx.render(cols, rows, 0, spp // 2, 50, 1)
+    _, st_b = ctx.render(cols, rows, spp // 2, spp // 2, 50, 1, flags=ra.FLAG_ACCUMULATE)
+    assert st_a["rays"] + st_b["rays"] == st["rays"] and st_a["term_depth"] + st_b["term_depth"] == st["term_depth"]
+    fb_split = ctx.resolve(spp)
+    diff = np.zeros(npix, dtype=np.int64)
+    for sh in (24, 16, 8):
+        diff = np.maximum(diff, np.abs(((fb_whole >> sh) & 0xFF).astype(np.int64) - ((fb_split >> sh) & 0xFF).astype(np.int64)))
+    assert diff.max() <= 1 and (diff != 0).mean() < 0.01
+    np.testing.assert_allclose(ctx.read_accum(), whole, rtol=3e-5, atol=1e-3)
