@@ -176,7 +176,7 @@ def run_group(args, result_fd):
     g = ra.Group([0] * n if loopback else list(range(n)))
     g.upload_scene(table)
     g.set_camera(ra.book_camera(cols, rows))
-    fb = np.zeros(cols * rows, dtype=np.uint32)
+    fb = g.member(0).host_framebuffer(cols * rows)    # pinned host memory mapped into GPU 0: the resolve kernel writes it over the host link
 
     def timed(spp_in_all, steps, warmup):
         for _ in range(warmup):
@@ -293,6 +293,9 @@ def main():
     ctx.set_camera(ra.book_camera(cols, rows))
     accum = TorchAccum(ctx, cols, rows, torch.device("cuda", local_rank))
     weak = args.weak or world == 1
+    # the host framebuffer (RayTracing.cpp:123-129; its CUDA mode takes it from the GPU runtime too, :125): pinned memory mapped
+    # into the GPU, so that the resolve kernel writes it over the host link
+    fb = ctx.host_framebuffer(cols * rows) if rank == 0 else None
 
     def share(weak_mode):
         """(first global sample, samples of this rank, samples of the image)"""
@@ -317,7 +320,7 @@ def main():
             if use_dist:
                 accum.allreduce()
             if rank == 0:
-                ctx.resolve(spp_total)
+                ctx.resolve(spp_total, out=fb)
             else:
                 ctx.sync()
 

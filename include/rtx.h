@@ -211,6 +211,16 @@ int rtx_load_accum(rtx_ctx* ctx, const char* path, uint32_t* cols, uint32_t* row
  * unpacks).  debug_tile != 0 paints tile borders 0xFF000000 as -d does (raytracer.cpp:168-171). */
 int rtx_resolve_rgbx8(rtx_ctx* ctx, uint32_t spp_total, uint32_t debug_tile, uint32_t* framebuffer_host);
 
+/* Host memory for framebuffers, pinned and mapped into the GPU (hipHostMalloc, portable + mapped): an rtx_resolve_rgbx8 whose
+ * framebuffer_host lies inside such a block is written by the resolve kernel itself over the host link -- no staging copy
+ * (0.36 -> about 0.1 ms per 1200 x 800 frame).  The reference's CUDA mode allocates its framebuffer through the GPU runtime in
+ * the same way (cudaMallocManaged, RayTracing.cpp:125; new[] otherwise, :127).  rtx_host_free or rtx_destroy releases the block;
+ * any other host memory keeps working as before, through a copy.  For a group: allocate through rtx_group_member(group, 0), the
+ * member that resolves.  (Pinning memory the caller already owns -- hipHostRegister -- is refused by the runtime on the
+ * machines this was built on, hence an allocator.) */
+int rtx_host_alloc(rtx_ctx* ctx, size_t bytes, void** host);
+int rtx_host_free(rtx_ctx* ctx, void* host);
+
 /* ---- several GPUs of one node (no counterpart in the reference, which is single-device) -------- */
 
 /* A group is one member context per listed device, in ONE process, plus -- for more than one device -- a RCCL communicator

@@ -17,7 +17,7 @@ FILTER_VALU, FILTER_MFMA, FILTER_GRID, FILTER_AUTO = 0, 1, 2, 3
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_scene", "rtx_set_filter", "rtx_set_tuning", "rtx_last_chunk_plan", "rtx_last_launch_ordered", "rtx_set_camera", "rtx_render",
            "rtx_render_noalloc", "rtx_render_async", "rtx_sync", "rtx_last_kernel_ms", "rtx_last_trace_ms", "rtx_use_accum_buffer", "rtx_accum_device", "rtx_read_accum", "rtx_write_accum",
-           "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks", "rtx_build_grid",
+           "rtx_save_accum", "rtx_load_accum", "rtx_resolve_rgbx8", "rtx_host_alloc", "rtx_host_free", "rtx_camera_init", "rtx_scene_capacity", "rtx_random_scene", "rtx_write_ppm", "rtx_write_ppm_p6", "rtx_plan_chunks", "rtx_build_grid",
            "rtx_version", "rtx_group_create", "rtx_group_destroy", "rtx_group_size", "rtx_group_member", "rtx_group_upload_scene", "rtx_group_set_camera",
            "rtx_group_render", "rtx_group_allreduce", "rtx_group_last_exchange_ms", "rtx_group_render_frame", "rtx_group_resolve_rgbx8", "rtx_spp_range"]
 
@@ -105,6 +105,8 @@ def lib():
     L.rtx_read_accum.argtypes = [C.c_void_p, fp, C.c_size_t]
     L.rtx_write_accum.argtypes = [C.c_void_p, u32, u32, fp, C.c_size_t]
     L.rtx_resolve_rgbx8.argtypes = [C.c_void_p, u32, u32, up]
+    L.rtx_host_alloc.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p)]
+    L.rtx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.rtx_camera_init.argtypes = [P(CCamera), f32, f32, f32, f32, fp, fp, fp]
     L.rtx_scene_capacity.restype = u32
     L.rtx_scene_capacity.argtypes = [C.c_int]
@@ -375,10 +377,20 @@ class Context:
         self.cols, self.rows = v[0].value, v[1].value
         return {"cols": v[0].value, "rows": v[1].value, "spp_done": v[2].value, "seed": seed.value, "max_depth": v[3].value, "flags": v[4].value}
 
-    def resolve(self, spp_total, debug_tile=0):
-        fb = np.zeros(self.cols * self.rows, dtype=np.uint32)
+    def resolve(self, spp_total, debug_tile=0, out=None):
+        fb = out if out is not None else np.zeros(self.cols * self.rows, dtype=np.uint32)
         _check(lib().rtx_resolve_rgbx8(self._h, spp_total, debug_tile, _up(fb)))
         return fb
+
+    def host_framebuffer(self, n_pixels):
+        """rtx_host_alloc: a uint32 array of n_pixels in pinned host memory mapped into the GPU; resolve(out=array) then needs no
+        staging copy.  The memory belongs to the context: do not use the array after host_free(array) or close()."""
+        p = C.c_void_p()
+        _check(lib().rtx_host_alloc(self._h, n_pixels * 4, C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n_pixels,))
+
+    def host_free(self, array):
+        _check(lib().rtx_host_free(self._h, C.c_void_p(array.ctypes.data)))
 
 
 def spp_range(rank, world, spp_begin, spp_count):

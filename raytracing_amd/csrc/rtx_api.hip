@@ -138,6 +138,8 @@ struct rtx_ctx {
     void*     sort_tmp = nullptr;  size_t sort_tmp_bytes = 0;
     unsigned long long* cost_total = nullptr;          // device: rays of the whole frame in the most recent launch (reduce_kernel)
     bool      last_ordered = false;                    // the most recent launch ran a cost-ordered work list
+    struct Pinned { char* host; size_t bytes; char* dev; };
+    std::vector<Pinned> pinned;                        // host memory mapped into the GPU (rtx_host_alloc)
 };
 
 extern "C" const char* rtx_last_error(void) { return g_last_error.c_str(); }
@@ -204,6 +206,7 @@ extern "C" int rtx_destroy(rtx_ctx* c)
     if (!c) return RTX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (const rtx_ctx::Pinned& p : c->pinned) (void)hipHostFree(p.host);
     void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->grid_cells, c->grid_geom, c->grid_items, c->grid_big, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats,
                      c->cost, c->order, c->sort_keys, c->sort_vals, c->sort_tmp, c->cost_total };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -1041,6 +1044,16 @@ extern "C" int rtx_resolve_rgbx8(rtx_ctx* c, uint32_t spp_total, uint32_t debug_
     if (spp_total == 0) return fail(RTX_ERR_ARG, "rtx_resolve_rgbx8: spp_total is 0");
     HIP_TRY(hipSetDevice(c->device));
     const size_t npix = (size_t)c->cols * c->rows;
+    // a framebuffer inside memory from rtx_host_alloc is written by the kernel itself, over the host link
+    for (const rtx_ctx::Pinned& p : c->pinned) {
+        const char* fbh = reinterpret_cast<const char*>(framebuffer_host);
+        if (fbh >= p.host && fbh + npix * sizeof(uint32_t) <= p.host + p.bytes) {
+            launch_resolve(c->accum, reinterpret_cast<uint32_t*>(p.dev + (fbh - p.host)), c->cols, c->rows, spp_total, debug_tile, c->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return RTX_OK;
+        }
+    }
     int rc = ensure(&c->fb, &c->fb_items, npix);
     if (rc) return rc;
     launch_resolve(c->accum, c->fb, c->cols, c->rows, spp_total, debug_tile, c->stream);
@@ -1048,6 +1061,36 @@ extern "C" int rtx_resolve_rgbx8(rtx_ctx* c, uint32_t spp_total, uint32_t debug_
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(framebuffer_host, c->fb, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return RTX_OK;
+}
+
+extern "C" int rtx_host_alloc(rtx_ctx* c, size_t bytes, void** host)
+{
+    if (!c || !host || bytes == 0) return fail(RTX_ERR_ARG, "rtx_host_alloc: NULL argument or empty size");
+    *host = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess || !p) { (void)hipGetLastError(); return fail(RTX_ERR_NOMEM, "rtx_host_alloc: hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); }
+    void* dev = nullptr;
+    e = hipHostGetDevicePointer(&dev, p, 0);
+    if (e != hipSuccess || !dev) { (void)hipHostFree(p); return fail(RTX_ERR_DEVICE, "rtx_host_alloc: hipHostGetDevicePointer failed: %s", hipGetErrorString(e)); }
+    c->pinned.push_back({ static_cast<char*>(p), bytes, static_cast<char*>(dev) });
+    *host = p;
+    return RTX_OK;
+}
+
+extern "C" int rtx_host_free(rtx_ctx* c, void* host)
+{
+    if (!c || !host) return fail(RTX_ERR_ARG, "rtx_host_free: NULL argument");
+    for (size_t i = 0; i < c->pinned.size(); ++i)
+        if (c->pinned[i].host == host) {
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipHostFree(host));
+            c->pinned.erase(c->pinned.begin() + (long)i);
+            return RTX_OK;
+        }
+    return fail(RTX_ERR_ARG, "rtx_host_free: %p was not allocated through this context", host);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -373,3 +373,26 @@ def test_config3_at_its_own_sample_count(ra, ctx, golden_scenes):
         diff = np.maximum(diff, np.abs(((fb_whole >> sh) & 0xFF).astype(np.int64) - ((fb_split >> sh) & 0xFF).astype(np.int64)))
     assert diff.max() <= 1 and (diff != 0).mean() < 0.01
     np.testing.assert_allclose(ctx.read_accum(), whole, rtol=3e-5, atol=1e-3)
+
+
+def test_resolve_into_pinned_host_memory(ra, ctx, golden_scenes):
+    """rtx_host_alloc: a framebuffer in pinned, GPU-mapped host memory is written by the resolve kernel itself; the pixels equal
+    those that arrive through the staging copy, also at an offset inside the block and with -d borders."""
+    cols, rows, spp = 200, 120, 5
+    ctx.upload_scene(golden_scenes["book1"])
+    ctx.set_camera(ra.book_camera(cols, rows))
+    ctx.render(cols, rows, 0, spp, 50, 3, want_stats=False)
+    want, want_d = ctx.resolve(spp), ctx.resolve(spp, 16)
+    block = ctx.host_framebuffer(cols * rows + 64)
+    block[:] = 0xDEADBEEF
+    got = ctx.resolve(spp, out=block[:cols * rows])
+    assert (got == want).all() and (block[cols * rows:] == 0xDEADBEEF).all()
+    block[:] = 0
+    ctx.resolve(spp, 16, out=block[64:])
+    assert (block[64:] == want_d).all() and not block[:64].any()
+    small = ctx.host_framebuffer(100)
+    with pytest.raises(ra.RtxError):
+        ctx.host_free(np.zeros(4, dtype=np.uint32))                      # not ours
+    ctx.host_free(small)
+    ctx.host_free(block)
+    assert ra.lib().rtx_host_alloc(ctx._h, 0, None) == -1               # RTX_ERR_ARG
