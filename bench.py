@@ -174,6 +174,8 @@ def run_group(args, result_fd):
     loopback = os.environ.get("RTX_GROUP_LOOPBACK", "0") not in ("", "0")
     table = ra.random_scene(SEED)
     g = ra.Group([0] * n if loopback else list(range(n)))
+    for r in range(n):
+        g.member(r).set_filter(ra.FILTER_MFMA)        # the headline is the reference's linear list (see main())
     g.upload_scene(table)
     g.set_camera(ra.book_camera(cols, rows))
     fb = g.member(0).host_framebuffer(cols * rows)    # pinned host memory mapped into GPU 0: the resolve kernel writes it over the host link
@@ -219,7 +221,9 @@ def run_group(args, result_fd):
         "config": {"workload": "book-1 final scene (seed 1, %d spheres) %dx%d, %s, depth %d" % (len(table), cols, rows, ("%d spp per GPU" % spp_total) if args.weak else ("%d spp in all" % spp_total), DEPTH),
                    "parallelism": ("REHEARSAL (RTX_GROUP_LOOPBACK): %d members on ONE device, exchange = plain sum; not a measurement" % n) if loopback
                                   else "spp split x%d in one process (rtx_group_*: ncclCommInitAll) + RCCL all-reduce of the float accumulation buffer" % n,
-                   "rays_per_sample": round(stats["rays"] / stats["samples"], 4)},
+                   "rays_per_sample": round(stats["rays"] / stats["samples"], 4),
+                   "candidate_search": "linear list: every ray against every sphere through the f16 MFMA filter (RTX_FILTER_MFMA, the north star's path)",
+                   "work_order": "cost-ordered from the second launch of the frame on (rtx_last_launch_ordered)"},
         "rccl_ranks": g.size(), "member_trace_ms": [round(m, 4) for m in member_ms], "exchange": exchange,
         "weak_scaling" if not args.weak else "strong_scaling": side,
         "roofline": roofline_block(len(table), per_launch, trace_avg_ms),
@@ -289,6 +293,11 @@ def main():
     cols, rows = args.cols, args.rows
     table = ra.random_scene(SEED)
     ctx = ra.Context(local_rank)
+    # BASELINE's north star and configuration 2 name the linear list ("world hit over the sphere list", "sphere table in LDS"):
+    # the headline measures THAT path -- every ray against every sphere through the f16 MFMA filter -- although the library's
+    # default (RTX_FILTER_AUTO) would walk the uniform grid for a table of this size (identical image, about 25 % faster:
+    # other_workloads reports it)
+    ctx.set_filter(ra.FILTER_MFMA)
     ctx.upload_scene(table)
     ctx.set_camera(ra.book_camera(cols, rows))
     accum = TorchAccum(ctx, cols, rows, torch.device("cuda", local_rank))
@@ -375,7 +384,9 @@ def main():
             "config": {"workload": "book-1 final scene (seed 1, %d spheres) %dx%d, %s, depth %d" % (len(table), cols, rows, ("%d spp per GPU" % args.spp) if weak else ("%d spp in all" % args.spp), DEPTH),
                        "parallelism": (("REHEARSAL: %d ranks over %d device(s), %s all-reduce; not a measurement" % (world, torch.cuda.device_count(), os.environ["RTX_DIST_BACKEND"])) if rehearsal
                                        else "spp split x%d, one process per GPU + RCCL all-reduce (torch.distributed nccl) of the float accumulation buffer" % world) if world > 1 else "1 GPU",
-                       "rays_per_sample": round(stats["rays"] / stats["samples"], 4)},
+                       "rays_per_sample": round(stats["rays"] / stats["samples"], 4),
+                       "candidate_search": "linear list: every ray against every sphere through the f16 MFMA filter (RTX_FILTER_MFMA, the north star's path; the library's default RTX_FILTER_AUTO walks the uniform grid for this table: other_workloads)",
+                       "work_order": "cost-ordered from the second launch of the frame on (rtx_last_launch_ordered)"},
             "roofline": roofline_block(len(table), stats, head["trace_ms"]),
         }
         if world > 1:

@@ -101,9 +101,11 @@ int rtx_upload_scene(rtx_ctx* ctx, uint32_t n,
                      const float* albedo_r_host, const float* albedo_g_host, const float* albedo_b_host,
                      const float* blur_host, const float* ior_host);
 
-/* Chooses the candidate filter (default RTX_FILTER_MFMA; the environment variable RTX_FILTER=valu|mfma|grid|auto overrides the
+/* Chooses the candidate search (default RTX_FILTER_AUTO; the environment variable RTX_FILTER=valu|mfma|grid|auto overrides the
  * default at rtx_create).  No counterpart in the reference: all forms feed the same exact sphere.cpp:68-102 test and keep the
- * minimum of (t, index), i.e. the winner of the linear loop of raytracer.cpp:285-304. */
+ * minimum of (t, index), i.e. the winner of the linear loop of raytracer.cpp:285-304, so the images are identical bit for bit;
+ * RTX_FILTER_MFMA is that linear loop over the whole list (what bench.py's headline measures), RTX_FILTER_GRID visits only the
+ * spheres near the ray. */
 int rtx_set_filter(rtx_ctx* ctx, int kind);
 
 /* Tuning knobs of the launch (no counterpart in the reference; results do not depend on them except through the order

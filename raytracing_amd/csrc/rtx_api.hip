@@ -97,7 +97,7 @@ struct rtx_ctx {
     bool        ev_open = false;      // ev_first recorded since the last sync
     // scene
     uint32_t n = 0, n_pad = 0, n_pad_mfma = 0;
-    int      filter = kFilterMfma;
+    int      filter = kFilterAuto;  // the linear list through the MFMA filter up to 256 spheres, the uniform grid above (identical results)
     bool     mfma_ok = false;       // the scene fits the f16 range of the MFMA filter
     float    mfma_scale = 1.0f;
     double   mfma_omax = 0.0;       // largest |o| (norm) of a ray origin the MFMA filter's f16 operands can carry

@@ -26,7 +26,7 @@ struct HipRenderOptions {
     uint64_t    seed = 1;
     int         device = 0;              // first GPU
     int         n_devices = 1;           // GPUs device .. device + n_devices - 1: samples split by index, one RCCL all-reduce per exchange
-    int         filter = -1;             // RTX_FILTER_* for the candidate search; -1 keeps the library's default (RTX_FILTER / the linear list through the MFMA filter)
+    int         filter = -1;             // RTX_FILTER_* for the candidate search; -1 keeps the library's default (RTX_FILTER, else RTX_FILTER_AUTO: linear list up to 256 spheres, uniform grid above)
     rtx_stats*  stats = nullptr;         // counters of the last pass
     unsigned    pass_spp = 0;            // > 0: progressive, this many samples per pass
     const char* checkpoint = nullptr;    // written after every pass (rtx_save_accum)

@@ -126,7 +126,9 @@ int main(int argc, char** argv)
         // slowest GPU's trace + reduce kernels.  mfma_frac: f16 matrix-core flop the linear list's filter issued (64 per ray and
         // sphere of the table padded to 128) against the dense f16 peak of the GPUs used; 0 when another candidate search ran.
         const size_t n_pad = (scene->objects.size() + 127) / 128 * 128;
-        const bool   linear = filter == RTX_FILTER_MFMA || (filter == -1 && !getenv("RTX_FILTER")) || (filter == RTX_FILTER_AUTO && scene->objects.size() < 257);
+        const char*  envf = getenv("RTX_FILTER");
+        const int    eff = filter >= 0 ? filter : (envf ? (std::string(envf) == "mfma" ? RTX_FILTER_MFMA : std::string(envf) == "auto" ? RTX_FILTER_AUTO : RTX_FILTER_GRID) : RTX_FILTER_AUTO);
+        const bool   linear = eff == RTX_FILTER_MFMA || (eff == RTX_FILTER_AUTO && scene->objects.size() < 257);
         const double mfma_frac = linear ? 64.0 * (double)tot.rays * (double)n_pad / (tot.kernel_ms * 1e-3) / (2.5e15 * gpus) : 0.0;
         printf("{\"msamples_per_s\": %.3f, \"mrays_per_s\": %.3f, \"kernel_ms\": %.3f, \"rays\": %llu, \"samples\": %llu, \"n_gpus\": %d, \"passes\": %u, \"mfma_frac_of_f16_peak\": %.4f, \"wall_s\": %.3f}\n",
                tot.samples / (tot.kernel_ms * 1e3), tot.rays / (tot.kernel_ms * 1e3), tot.kernel_ms, (unsigned long long)tot.rays, (unsigned long long)tot.samples, gpus, tot_passes, mfma_frac, sec);

@@ -225,6 +225,7 @@ def test_bench_workload_properties(ra, ctx, golden_scenes):
     repeatability, additivity over a split of the sample range (two chunks of 250 = two accumulated launches of 250), and
     agreement of the automatic chunking (64 chunks, another summation order) to float accuracy."""
     cols, rows, spp = 1200, 800, 500
+    ctx.set_filter(ra.FILTER_MFMA)                                       # bench.py's headline path: the linear list
     ctx.upload_scene(golden_scenes["book1"])
     ctx.set_camera(ra.book_camera(cols, rows))
     _, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=250)
@@ -254,6 +255,7 @@ def test_config5_full_size_properties(ra, ctx, golden_scenes, monkeypatch):
     table (default at this size) against per-wave reads of the table and against the VALU filter, bit for bit."""
     cols, rows, spp = 1200, 800, 100
     table = golden_scenes["scaled"]
+    ctx.set_filter(ra.FILTER_MFMA)                                       # the linear list that the configuration names (the default would walk the grid)
     ctx.upload_scene(table)
     ctx.set_camera(ra.book_camera(cols, rows))
     _, st = ctx.render(cols, rows, 0, spp, 50, 1, chunk_spp=4)

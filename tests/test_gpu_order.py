@@ -100,6 +100,7 @@ def test_share_of_one_of_eight_gpus_on_the_bench_frame(ra, ctx, golden_scenes):
     most 16 chunks (the first, with the geometric plan, has more) and, where both use the same chunks, equals an unordered
     launch bit for bit; counters are identical."""
     cols, rows, depth, seed = 1200, 800, 50, 1
+    ctx.set_filter(ra.FILTER_MFMA)                                       # bench.py's path (the chunk sizes depend on the kernel's resident lanes)
     ctx.upload_scene(golden_scenes["book1"])
     ctx.set_camera(ra.book_camera(cols, rows))
     spp = 66
