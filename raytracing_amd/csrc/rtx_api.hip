@@ -9,6 +9,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -626,7 +632,9 @@ static int order_for_launch(rtx_ctx* c, const FrameKey& key, uint32_t chunk_spp,
     if (chunk_spp != 0) return RTX_OK;
     const size_t npix = (size_t)key.cols * key.rows, nstrips = (npix + 63) / 64;
     const bool have_cost = c->cost && c->cost_spp != 0 && c->cost_key == key && c->cost_items >= nstrips;
-    if (have_cost && c->cost_fresh) {
+    const bool have_order0 = c->order && c->order_cost_spp != 0 && c->order_key == key;
+    // (the steady state of a render loop -- a list built from a map at least as good as the new one -- needs no read-back)
+    if (have_cost && c->cost_fresh && !(have_order0 && c->cost_mean_rays > 0.0 && c->cost_spp <= c->order_cost_spp)) {
         // the frame's rays per sample, once per cost map.  Waits for the launch that wrote it.
         unsigned long long total = 0;
         HIP_TRY(hipMemcpyAsync(&total, c->cost_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
@@ -1097,8 +1105,72 @@ extern "C" int rtx_host_free(rtx_ctx* c, void* host)
 // Several GPUs of one node behind the C ABI: one process, one member context per device, the
 // samples of every pixel split over the members by global sample index, ONE RCCL all-reduce (sum, float32) of the
 // accumulation buffers over xGMI, resolve on member 0.  The reference has no counterpart (it is single-device).
+// One host thread per member beyond the first: the members' launches are queued side by side instead of one device after
+// the other (a launch sequence is about ten runtime calls, 40-60 us: queued from one thread, the eighth GPU of a node would
+// start 0.4 ms after the first -- 5 % of a 62-sample share).  A worker runs one task at a time and keeps the error message
+// of a failed task (rtx_last_error is per thread) for the caller.
+struct GroupWorker {
+    std::thread             th;
+    std::mutex              m;
+    std::condition_variable cv;
+    std::function<int()>    task;
+    bool                    has_task = false, done = true, quit = false;
+    int                     rc = 0;
+    std::string             err;
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_task || quit; });
+            if (quit) return;
+            std::function<int()> t = std::move(task);
+            has_task = false;
+            lk.unlock();
+            const int r = t();
+            const std::string e = r ? g_last_error : std::string();
+            lk.lock();
+            rc = r; err = e; done = true;
+            cv.notify_all();
+        }
+    }
+    void start() { th = std::thread([this] { loop(); }); }
+    void post(std::function<int()> t)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        task = std::move(t); has_task = true; done = false;
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct rtx_group {
     std::vector<rtx_ctx*>   members;
+    std::vector<std::unique_ptr<GroupWorker>> workers;   // workers[r - 1] serves member r
+    double                  last_enqueue_us = 0.0;       // host time of the most recent group_enqueue_render (diagnostic)
+    // fn(r) for every member, member 0 on the calling thread, the others on their workers; the first failure's code and message
+    int for_each_member(const std::function<int(uint32_t)>& fn)
+    {
+        const uint32_t world = (uint32_t)members.size();
+        for (uint32_t r = 1; r < world; ++r) workers[r - 1]->post([&fn, r] { return fn(r); });
+        int rc = fn(0);
+        std::string err = rc ? g_last_error : std::string();
+        for (uint32_t r = 1; r < world; ++r) {
+            const int rr = workers[r - 1]->wait();
+            if (rr && !rc) { rc = rr; err = workers[r - 1]->err; }
+        }
+        if (rc) g_last_error = err;
+        return rc;
+    }
     std::vector<ncclComm_t> comms;        // empty for a group of one: its all-reduce is the identity
     bool                    loopback = false;   // RTX_GROUP_LOOPBACK=1: several members on ONE device, exchange without RCCL (rehearsal)
     hipEvent_t              ex0 = nullptr, ex1 = nullptr;   // on member 0's stream, around its part of the most recent exchange
@@ -1131,6 +1203,7 @@ extern "C" void rtx_spp_range(uint32_t rank, uint32_t world, uint32_t spp_begin,
 extern "C" int rtx_group_destroy(rtx_group* g)
 {
     if (!g) return RTX_OK;
+    for (auto& w : g->workers) w->stop();
     for (size_t i = 0; i < g->comms.size(); ++i) {
         if (g->members[i]) (void)hipSetDevice(g->members[i]->device);
         if (g->comms[i]) (void)ncclCommDestroy(g->comms[i]);
@@ -1167,6 +1240,10 @@ extern "C" int rtx_group_create(const int* device_ids, int n_devices, rtx_group*
         const int rc = rtx_create(device_ids[i], &g->members[(size_t)i]);
         if (rc) { rtx_group_destroy(g); return rc; }           // rtx_create has set the message
     }
+    for (int i = 1; i < n_devices; ++i) {
+        g->workers.emplace_back(new GroupWorker());
+        g->workers.back()->start();
+    }
     // RTX_GROUP_RCCL=1 makes a group of ONE device go through RCCL too (a communicator of one rank): the rehearsal of the
     // exchange on a single-GPU box; without it a group of one never touches RCCL
     const char* force = getenv("RTX_GROUP_RCCL");
@@ -1199,11 +1276,8 @@ extern "C" int rtx_group_upload_scene(rtx_group* g, uint32_t n, const float* cx,
                                       const uint32_t* mat_type, const float* ar, const float* ag, const float* ab, const float* blur, const float* ior)
 {
     if (!g) return fail(RTX_ERR_ARG, "rtx_group_upload_scene: group is NULL");
-    for (rtx_ctx* c : g->members) {
-        const int rc = rtx_upload_scene(c, n, cx, cy, cz, radius, mat_type, ar, ag, ab, blur, ior);
-        if (rc) return rc;
-    }
-    return RTX_OK;
+    // (every member builds its own tables and grid: side by side on the members' host threads)
+    return g->for_each_member([&](uint32_t r) { return rtx_upload_scene(g->members[r], n, cx, cy, cz, radius, mat_type, ar, ag, ab, blur, ior); });
 }
 
 extern "C" int rtx_group_set_camera(rtx_group* g, const rtx_camera* cam)
@@ -1216,39 +1290,52 @@ extern "C" int rtx_group_set_camera(rtx_group* g, const rtx_camera* cam)
     return RTX_OK;
 }
 
-// Queues every member's share of the sample range on its own stream, device after device, and waits for nothing: the
-// launches of all devices run side by side.
+static int member_enqueue_render(rtx_group* g, uint32_t r, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+                                 uint64_t seed, uint32_t flags, uint32_t chunk_spp, bool want_stats)
+{
+    const uint32_t world = (uint32_t)g->members.size();
+    rtx_ctx* c = g->members[r];
+    uint32_t begin = 0, count = 0;
+    rtx_spp_range(r, world, spp_begin, spp_count, &begin, &count);
+    HIP_TRY(hipSetDevice(c->device));                        // every per-member call below runs with the member's device current
+    if (c->ev_open) { double dummy; const int rc0 = rtx_last_kernel_ms(c, &dummy); if (rc0) return rc0; }
+    if (count) {
+        const int rc = enqueue_render(c, cols, rows, begin, count, max_depth, seed, flags, chunk_spp, false, want_stats);
+        if (rc) return rc;
+    } else if (!(flags & RTX_FLAG_ACCUMULATE)) {
+        // more devices than samples: this member contributes zeros (it still takes part in the all-reduce)
+        if (c->cols != cols || c->rows != rows) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->accum_borrowed) {
+            if (c->accum_floats != (size_t)cols * rows * 3) return fail(RTX_ERR_STATE, "rtx_group_render: a member's borrowed accumulation buffer has the wrong size");
+        } else {
+            const int rc = ensure(&c->accum, &c->accum_floats, (size_t)cols * rows * 3);
+            if (rc) return rc;
+        }
+        c->cols = cols; c->rows = rows;
+        HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)cols * rows * 3 * sizeof(float), c->stream));
+        if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
+    } else if (c->cols != cols || c->rows != rows || !c->accum) {
+        return fail(RTX_ERR_STATE, "rtx_group_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
+    }
+    return RTX_OK;
+}
+
+// Queues every member's share of the sample range on its own stream -- every member from its own host thread -- and waits
+// for nothing on the devices: the launches of all GPUs run side by side.
 static int group_enqueue_render(rtx_group* g, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
                                 uint64_t seed, uint32_t flags, uint32_t chunk_spp, bool want_stats)
 {
     if (cols == 0 || rows == 0 || spp_count == 0) return fail(RTX_ERR_ARG, "rtx_group_render: cols, rows and spp_count must be non-zero");
-    const uint32_t world = (uint32_t)g->members.size();
-    for (uint32_t r = 0; r < world; ++r) {
-        rtx_ctx* c = g->members[r];
-        uint32_t begin = 0, count = 0;
-        rtx_spp_range(r, world, spp_begin, spp_count, &begin, &count);
-        HIP_TRY(hipSetDevice(c->device));                        // every per-member call below runs with the member's device current
-        if (c->ev_open) { double dummy; const int rc0 = rtx_last_kernel_ms(c, &dummy); if (rc0) return rc0; }
-        if (count) {
-            const int rc = enqueue_render(c, cols, rows, begin, count, max_depth, seed, flags, chunk_spp, false, want_stats);
-            if (rc) return rc;
-        } else if (!(flags & RTX_FLAG_ACCUMULATE)) {
-            // more devices than samples: this member contributes zeros (it still takes part in the all-reduce)
-            if (c->cols != cols || c->rows != rows) HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->accum_borrowed) {
-                if (c->accum_floats != (size_t)cols * rows * 3) return fail(RTX_ERR_STATE, "rtx_group_render: a member's borrowed accumulation buffer has the wrong size");
-            } else {
-                const int rc = ensure(&c->accum, &c->accum_floats, (size_t)cols * rows * 3);
-                if (rc) return rc;
-            }
-            c->cols = cols; c->rows = rows;
-            HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)cols * rows * 3 * sizeof(float), c->stream));
-            if (want_stats) HIP_TRY(hipMemsetAsync(c->stats, 0, (kStCount + 12) * sizeof(unsigned long long), c->stream));
-        } else if (c->cols != cols || c->rows != rows || !c->accum) {
-            return fail(RTX_ERR_STATE, "rtx_group_render: RTX_FLAG_ACCUMULATE needs a previous render of the same size");
-        }
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = RTX_OK;
+    if (getenv("RTX_GROUP_SERIAL")) {        // diagnostic: one device after the other from the calling thread (round 2's behaviour)
+        for (uint32_t r = 0; r < (uint32_t)g->members.size() && rc == RTX_OK; ++r) rc = member_enqueue_render(g, r, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, want_stats);
+    } else {
+        rc = g->for_each_member([&](uint32_t r) { return member_enqueue_render(g, r, cols, rows, spp_begin, spp_count, max_depth, seed, flags, chunk_spp, want_stats); });
     }
-    return RTX_OK;
+    g->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipSetDevice(g->members[0]->device);
+    return rc;
 }
 
 extern "C" int rtx_group_render(rtx_group* g, uint32_t cols, uint32_t rows, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
@@ -1357,6 +1444,9 @@ extern "C" int rtx_group_allreduce(rtx_group* g)
     if (rc) return rc;
     return group_sync(g);
 }
+
+// Diagnostic (tools/ only, not declared in rtx.h): host microseconds the most recent rtx_group_render / _render_frame spent queueing the members' launches.
+extern "C" double rtx_debug_group_enqueue_us(const rtx_group* g) { return g ? g->last_enqueue_us : 0.0; }
 
 extern "C" int rtx_group_last_exchange_ms(rtx_group* g, double* ms)
 {
