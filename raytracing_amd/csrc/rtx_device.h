@@ -25,7 +25,9 @@ constexpr uint32_t kChunkTabBytes = 256;               // the LDS copy of the bo
 // themselves (d'_i d'_j, o.d' d'_i - o_i, |o|^2 - (o.d')^2) carry <= 5 ulp from d' and o.d'.  Quadratic part: 17 ulp of
 // (sum |C_i d'_i|)^2 <= 17 |C|^2; linear part: 17 ulp of 4 |C||o| <= 34; K'' 4; constant 8 |o|^2; accumulation of the two
 // chained v_mfma_f32_32x32x16_f16 (<= 5.7 ulp of sum |terms| each, tools/microbench/mfma_f16_error.hip, sum |terms| <=
-// 4 (|C|^2 + |o|^2)) 46; the reference's own rounding of b*b - a*c moves the sign within 34.  Sum 143 of 256.
+// 4 (|C|^2 + |o|^2)) 46; the reference's own rounding of b*b - a*c moves the sign within 34.  Sum 143 of 256.  Worst case of
+// a model instead of the measurement -- exact f16 x f16 products, 16 additions per MFMA each rounded to nearest in any order:
+// 16 ulp per MFMA, 128 for the two -- gives 225 of 256: the margin also holds there ("filter margins").
 // kMfmaAbsMargin covers f16 subnormals: second parts below 2^-14 are rounded to multiples of 2^-24, which against a
 // partner of up to 2^16 is 2^-9 (in scale^2 units) per slot pair; ten monomials.
 constexpr double   kMfmaAbsMargin = 0.03125;                         // 2^-5
