@@ -65,3 +65,54 @@ def test_random_scene_matches_oracle(ra, oracle, case):
         assert same.all(), (case, kind, int((~same).sum()))
         for k in ("samples", "rays", "term_miss", "term_absorb", "term_depth"):
             assert st[k] == o_st[k], (case, kind, k)
+
+
+_ORDERED_SEEN = []
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_scene_second_launch_matches_oracle_whatever_the_work_order(ra, oracle, case):
+    """The second and third launches of a frame run a cost-ordered work list when the frame carries enough work (round 3).
+    Random scenes, cameras, sizes, sample ranges, depths, -r, the three candidate searches, odd chunk limits: each launch must
+    equal the oracle summing in the chunks the library reports, bit for bit -- the order in which the work is handed out must
+    never show."""
+    rng = np.random.default_rng(5000 + case)
+    n = int(rng.choice([3, 31, 64, 129, 300]))
+    table = _random_table(rng, n)
+    cols, rows = int(rng.integers(280, 460)), int(rng.integers(190, 300))       # enough work per resident lane for three-sample chunks
+    spp, depth, seed = int(rng.integers(12, 30)), int(rng.choice([3, 8, 8, 50])), 900 + case
+    pos = rng.uniform(-1.5, 1.5, size=3).astype(np.float32) * np.float32(table[:, 0:3].max() + 3.0)
+    look = table[0, 0:3] + np.float32(0.25)
+    args = (np.float32(rng.uniform(15, 80)), np.float32(cols) / np.float32(rows), np.float32(rng.uniform(0.0, 0.3)), np.float32(rng.uniform(1, 30)), pos, (0, 1, 0), look.astype(np.float32))
+    cam, ocam = ra.Camera(*args), oracle.camera(*args)
+    rec = bool(case % 6 == 5)
+    kind = (ra.FILTER_MFMA, ra.FILTER_GRID, ra.FILTER_VALU, ra.FILTER_AUTO)[case % 4]
+    ctx = ra.Context(0)
+    try:
+        ctx.set_filter(kind)
+        ctx.set_tuning("order_share_pct", int(rng.choice([200, 400])))
+        ctx.set_tuning("order_chunks", int(rng.choice([2, 5, 16, 63])))
+        ctx.upload_scene(table)
+        ctx.set_camera(cam)
+        flags = ra.FLAG_RECURSIVE if rec else 0
+        begin = 0
+        for launch in range(3):
+            count = spp if launch < 2 else spp + 3
+            primary, st = ctx.render(cols, rows, begin, count, depth, seed, flags=flags, want_primary=True)
+            _ORDERED_SEEN.append(ctx.last_launch_ordered())
+            assert not (launch == 0 and _ORDERED_SEEN[-1])
+            chunk_spp, starts = ctx.last_chunk_plan()
+            assert chunk_spp == 0 and starts[-1] == count
+            o_accum, o_primary, o_st = oracle.render(table, ocam, rows, cols, begin, count, depth, seed, recursive=rec, want_primary=True, chunk_starts=starts)
+            accum = ctx.read_accum()
+            assert (primary == o_primary).all(), (case, launch)
+            same = (bits(accum) == bits(o_accum)) | (np.isnan(accum) & np.isnan(o_accum))
+            assert same.all(), (case, launch, int((~same).sum()))
+            for k in ("samples", "rays", "term_miss", "term_absorb", "term_depth"):
+                assert st[k] == o_st[k], (case, launch, k)
+            if launch == 1:
+                begin = spp                                  # the third launch: the next sample range of the same frame
+    finally:
+        ctx.close()
+    if case == 15:
+        assert sum(_ORDERED_SEEN) >= 10, sum(_ORDERED_SEEN)      # the cases do exercise ordered launches
