@@ -37,6 +37,9 @@ static thread_local std::string g_last_error;
 // rtx_render_noalloc: one flag per device, raised while a call of this process uses that device's scratch array
 constexpr int kMaxScratchDevices = 64;
 static std::atomic<bool> g_scratch_busy[kMaxScratchDevices];
+#ifdef RTX_WALK_STATS
+static unsigned long long* g_walk_stats = nullptr;      // diagnostic build: 64 counters of the grid walk, one device, one context at a time
+#endif
 #ifdef RTX_WAVE_TIMES
 static unsigned long long* g_wave_times = nullptr;      // diagnostic build: 5 words per wave, one device, one context at a time
 #endif
@@ -74,6 +77,7 @@ struct Tuning {
     int order_chunks = 16;      // most sample chunks of a cost-ordered launch
     int order_share_pct = 50;   // share of the launch's expected duration that its single longest item may take, in per cent
     int tail_guard = 4;         // reservations are made on demand (not ahead of time) within this many items per resident lane of the list's end
+    int walk_park = 10;         // grid variant: the walks of a wave's last walk_park rays are parked in LDS while the wave shades the rest (0: never; book-1 is best at 8, 20 164 spheres at 12)
 };
 
 // What identifies "the same frame" for the pixel-cost map: scene, camera and image size.
@@ -178,7 +182,7 @@ extern "C" int rtx_create(int device_id, rtx_ctx** out_ctx)
         { "RTX_BLOCK", "block" }, { "RTX_STREAM", "stream" }, { "RTX_LDS_PAD", "lds_pad" }, { "RTX_ITEMS_PER_LANE", "items_per_lane" },
         { "RTX_MAX_CHUNKS", "max_chunks" }, { "RTX_WAVE_BATCH", "wave_batch" }, { "RTX_TAIL_FACTOR", "tail_factor" },
         { "RTX_PARTIALS_MB", "partials_mb" }, { "RTX_PRINT_PHASES", "print_phases" }, { "RTX_GRID_DENSITY_PCT", "grid_density_pct" },
-        { "RTX_TAIL_GUARD", "tail_guard" }, { "RTX_ORDER", "order" }, { "RTX_ORDER_CHUNKS", "order_chunks" }, { "RTX_ORDER_SHARE_PCT", "order_share_pct" } };
+        { "RTX_TAIL_GUARD", "tail_guard" }, { "RTX_WALK_PARK", "walk_park" }, { "RTX_ORDER", "order" }, { "RTX_ORDER_CHUNKS", "order_chunks" }, { "RTX_ORDER_SHARE_PCT", "order_share_pct" } };
     for (const auto& kv : kEnv)
         if (const char* v = getenv(kv.env)) {
             char* end = nullptr;
@@ -389,6 +393,7 @@ extern "C" int rtx_set_tuning(rtx_ctx* c, const char* key, int value)
     else if (k == "grid_density_pct") { ok = value >= 1 && value <= 6400; if (ok) t.grid_density_pct = value; }
     else if (k == "tail_guard")     { ok = value >= 0 && value <= 4096; if (ok) t.tail_guard = value; }
     else if (k == "order")          { ok = value == 0 || value == 1; if (ok) t.order = value; }
+    else if (k == "walk_park")      { ok = value >= 0 && value <= 32; if (ok) t.walk_park = value; }
     else if (k == "order_chunks")   { ok = value >= 1 && value <= (int)kMaxPlanChunks; if (ok) t.order_chunks = value; }
     else if (k == "order_share_pct") { ok = value >= 1 && value <= 400; if (ok) t.order_share_pct = value; }
     else return fail(RTX_ERR_ARG, "rtx_set_tuning: unknown knob '%s'", key);
@@ -579,6 +584,7 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
     P.cols = cols; P.rows = rows; P.npix = R.npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = R.nchunks;
     P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = R.n_items; P.wave_batch = wave_batch;
     P.tail_guard = (uint32_t)std::min<uint64_t>((uint64_t)c->tune.tail_guard * lanes, 1ull << 30);
+    P.walk_park = (uint32_t)c->tune.walk_park;
     if (flags & RTX_FLAG_RECURSIVE) R.att_entries = (uint64_t)std::max<uint32_t>(max_depth, 1u) * R.lp.max_grid * R.lp.block;
     const uint32_t blocks_needed = (uint32_t)((n_items64 + R.lp.block - 1) / R.lp.block);
     R.grid = std::max<uint32_t>(1, std::min<uint32_t>(R.lp.max_grid, blocks_needed));
@@ -604,6 +610,10 @@ static int launch_render(rtx_ctx* c, RenderSetup& R, const RenderBuffers& B, uin
 #ifdef RTX_WAVE_TIMES
     if (!g_wave_times) { HIP_TRY(hipMalloc(&g_wave_times, 9u * 65536u * 8u)); HIP_TRY(hipMemset(g_wave_times, 0, 9u * 65536u * 8u)); }
     P.wave_times = g_wave_times;
+#endif
+#ifdef RTX_WALK_STATS
+    if (!g_walk_stats) { HIP_TRY(hipMalloc(&g_walk_stats, 128u * 8u)); HIP_TRY(hipMemset(g_walk_stats, 0, 128u * 8u)); }
+    P.walk_stats = g_walk_stats;
 #endif
     HIP_TRY(hipMemsetAsync(B.work_counter, 0, 256, c->stream));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
@@ -853,6 +863,28 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
     double ms = 0.0;
     rc = rtx_last_kernel_ms(c, &ms);
     if (rc) return rc;
+#ifdef RTX_WALK_STATS
+    if (g_walk_stats && getenv("RTX_PRINT_WALK")) {
+        unsigned long long w[128];
+        HIP_TRY(hipMemcpy(w, g_walk_stats, sizeof(w), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(g_walk_stats, 0, sizeof(w)));
+        auto avg = [&](int a, int b) { return w[b] ? (double)w[a] / (double)w[b] : 0.0; };
+        fprintf(stderr, "walk: iterations %llu (%.1f rays each), trips %llu = %.1f per iteration, %.1f rays walking per trip\n", w[0], avg(1, 0), w[2], avg(2, 0), avg(3, 2));
+        fprintf(stderr, "  per trip: cell load run %.2f (%.1f lanes)  test %.2f (%.1f lanes)  root %.2f (%.1f lanes)  step %.2f (%.1f lanes)\n",
+                avg(4, 2), avg(5, 4), avg(6, 2), avg(7, 6), avg(10, 2), avg(11, 10), avg(8, 2), avg(9, 8));
+        fprintf(stderr, "  per ray: trips %.2f  cells %.2f  tests %.2f  roots %.2f   lane-trips / (64 x trips) = %.3f\n", avg(3, 1), avg(5, 1), avg(7, 1), avg(11, 1), (double)w[3] / (64.0 * (double)w[2]));
+        const char* names[4] = { "trips of an iteration", "trips of a ray", "cells of a ray", "tests of a ray" };
+        for (int h = 0; h < 4; ++h) {
+            unsigned long long tot = 0; for (int k = 0; k < 9; ++k) tot += w[16 + 9 * h + k];
+            fprintf(stderr, "  %-22s 0: %4.1f %%  1: %4.1f  2-3: %4.1f  4-7: %4.1f  8-15: %4.1f  16-31: %4.1f  32-63: %4.1f  64-127: %4.1f  128+: %4.1f\n", names[h],
+                    100.0 * w[16 + 9 * h] / tot, 100.0 * w[17 + 9 * h] / tot, 100.0 * w[18 + 9 * h] / tot, 100.0 * w[19 + 9 * h] / tot, 100.0 * w[20 + 9 * h] / tot,
+                    100.0 * w[21 + 9 * h] / tot, 100.0 * w[22 + 9 * h] / tot, 100.0 * w[23 + 9 * h] / tot, 100.0 * w[24 + 9 * h] / tot);
+        }
+        fprintf(stderr, "  rays by trips 0..63+:");
+        for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", w[64 + k]);
+        fprintf(stderr, "\n");
+    }
+#endif
 #ifdef RTX_WAVE_TIMES
     if (g_wave_times && getenv("RTX_PRINT_WAVES")) {
         // diagnostic build: when do the waves run dry and end, relative to the first wave's start (100 MHz clock -> microseconds)
@@ -892,7 +924,7 @@ extern "C" int rtx_render(rtx_ctx* c, uint32_t cols, uint32_t rows, uint32_t spp
         unsigned long long h[kStCount + 12];
         HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
         if (c->tune.print_phases) {
-            static const char* names[12] = { "A fetch", "B camera", "C filter tiles", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish", "C filter setup", "C push words", "C peel + enqueue", "C exact batches" };
+            static const char* names[12] = { "A fetch", "B camera", "C filter tiles", "C exact", "D hit fetch", "D sphere rng", "D material", "E finish", "C filter setup", "C push words", "C peel + enqueue", "C exact batches" };      // (grid variant: C filter tiles = the walk, C exact = full scans, C filter setup = big list, C push words = walk set-up)
             unsigned long long tot = 0;
             for (int k = 0; k < 12; ++k) tot += h[kStCount + k];
             for (int k = 0; k < 12 && tot; ++k) fprintf(stderr, "phase %-18s %6.2f %%\n", names[k], 100.0 * (double)h[kStCount + k] / (double)tot);

@@ -18,6 +18,7 @@ constexpr uint32_t kMaxBlock   = 512;                  // threads per workgroup 
 constexpr uint32_t kWaveBatch  = 64;                    // smallest reservation of work items (TraceParams::wave_batch)
 constexpr uint32_t kWaveLdsBytes = 4608;               // per wave: 64 ray records (2 KB), 64 result slots (512 B), 256 candidate entries (1 KB), 128 sign-word entries (1 KB)
 constexpr uint32_t kNoHit      = 0xFFFFFFFFu;
+constexpr uint32_t kWaveLdsBytesGrid = 2304 + 13 * 256;    // grid variant: phase (D)'s cooperative sampling (2304 B), then 13 parked words per lane
 constexpr uint32_t kChunkTabBytes = 256;               // the LDS copy of the boundaries, in front of everything else
 // MFMA filter: absolute margin gamma * (|C|^2 + r^2 + |K'|) + kMfmaAbsMargin / scale^2 per sphere and gamma * |o|^2 per
 // ray, gamma = 2^-16 = 256 ulp (ulp = 2^-24).  Budget, in ulp of (|C|^2 + |o|^2), for the single quadratic form: a monomial
@@ -49,6 +50,8 @@ constexpr uint32_t kMaxLdsSpheres = 2048;              // VALU filter: 16 B/sphe
 #endif
 constexpr uint32_t kMaxLdsSpheresMfma = RTX_MAX_LDS_MFMA;          // MFMA filter: 64 B/sphere (+ 16 B exact record)
 
+__host__ __device__ constexpr uint32_t wave_lds_bytes(int filter) { return filter == kFilterGrid ? kWaveLdsBytesGrid : kWaveLdsBytes; }
+
 enum StatSlot { kStSamples = 0, kStRays, kStMiss, kStAbsorb, kStDepth, kStCandidates, kStFilterMiss, kStCount };
 
 struct TraceParams {
@@ -72,6 +75,7 @@ struct TraceParams {
     uint32_t      n_items;
     uint32_t      wave_batch; // work items a wave reserves per trip to the global counter (host: about 512 samples' worth)
     uint32_t      tail_guard; // the last tail_guard items of the list are reserved on demand instead of ahead of time
+    uint32_t      walk_park;  // grid variant: park the walks of the last walk_park rays of a wave (0: every walk runs to its end in its own iteration)
     const uint32_t* order;    // NULL: item it = (chunk it / npix, pixel it % npix); else cost-ordered batches of 64 items: items 64 b .. 64 b + 63 are
                               // chunk order[b] >> 22 of the pixels 64 s .. 64 s + 63 of strip s = order[b] & 0x3FFFFF
     float4*       partials;   // n_items x (sum r, g, b, rays as uint bits): item = chunk * npix + pixel
@@ -81,6 +85,9 @@ struct TraceParams {
     unsigned long long* stats; // kStCount counters
 #ifdef RTX_WAVE_TIMES
     unsigned long long* wave_times;   // diagnostic build: 5 words per wave
+#endif
+#ifdef RTX_WALK_STATS
+    unsigned long long* walk_stats;   // diagnostic build (grid walk): 64 counters, see trace_kernel.hip
 #endif
 };
 

@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 #define RTX_STAMP(slot) do { } while (0)
 #endif
 
-enum LaneState : uint32_t { kNeedItem = 0, kNeedSample = 1, kTrace = 2, kDead = 3 };
+enum LaneState : uint32_t { kNeedItem = 0, kNeedSample = 1, kTrace = 2, kDead = 3, kWalking = 4 };     // kWalking (grid variant): the ray's walk is parked in LDS and goes on in the next iteration
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();
     // per wave (kWaveLdsBytes): 64 ray records in two planes, (o, a) and (d, -), that the candidate re-test gathers from -- the MFMA filter
     // first uses the same 2 KB to hand its per-ray operands around --, 64 result slots, and the candidate queue
-    wave_lds += wave * (kWaveLdsBytes / 16u);
+    wave_lds += wave * (wave_lds_bytes(FILTER) / 16u);
     float4* const             rayrec = wave_lds;
     float* const              xbuf   = reinterpret_cast<float*>(wave_lds);
     unsigned long long* const res    = reinterpret_cast<unsigned long long*>(wave_lds + 128);
@@ -214,6 +214,13 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
 #ifdef RTX_PHASE_TIMERS
     uint64_t ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     uint64_t ph_last = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef RTX_WALK_STATS
+    // diagnostic build (grid walk): lane k keeps counter k of P.walk_stats[0..11] (ws_acc) and of the four 9-bucket histograms at [16..51] (ws_hist)
+    uint32_t ws_acc = 0u, ws_hist = 0u, ws_lin = 0u;      // ws_lin: lane k counts the rays that needed k loop trips (63: or more), P.walk_stats[64..127]
+#define WS_ADD(slot, v) do { if (lane == (uint32_t)(slot)) ws_acc += (uint32_t)(v); } while (0)
+#define WS_HIST(h, n, active) do { const uint32_t bk_ = (n) == 0u ? 0u : (32u - (uint32_t)__clz((int)(n)) > 8u ? 8u : 32u - (uint32_t)__clz((int)(n))); \
+        for (uint32_t b_ = 0; b_ < 9u; ++b_) { const uint32_t c_ = (uint32_t)__popcll(__ballot((active) && bk_ == b_)); if (lane == 9u * (h) + b_) ws_hist += c_; } } while (0)
 #endif
 #ifdef RTX_WAVE_TIMES
     // diagnostic build: per wave (start, counter seen dry, end) on the chip-wide 100 MHz clock + iterations + lane-iterations spent tracing
@@ -346,14 +353,15 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         }
 
         RTX_STAMP(1);
-        const bool     tracing = (st == kTrace);
-        const uint64_t tmask   = __ballot(tracing);
+        const bool     tracing  = (st == kTrace);                                    // rays that start their _sceneHit in this iteration
+        const uint64_t tmask    = __ballot(tracing);
+        const uint64_t amask    = (FILTER == kFilterGrid) ? __ballot(tracing || st == kWalking) : tmask;     // grid variant: + the rays whose walk was parked in an earlier iteration
         if (STREAM) {
             // the waves of a workgroup walk the table together (barriers in the filter loop), so they also stop together;
             // this barrier also separates the previous iteration's reads of the stage from the next fill
             if (!__syncthreads_or(tmask != 0ull)) break;
         } else {
-            if (!tmask) break;      // every lane is kDead: the queue is drained and all paths have ended
+            if (!amask) break;      // every lane is kDead: the queue is drained and all paths have ended
         }
         c_rays += (uint64_t)__popcll(tmask);
         item_rays += tracing ? 1u : 0u;
@@ -375,6 +383,9 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             // only when the closest hit so far lies more than twice the walk's own slack before the exit of the cell just
             // finished (the accepted root of an untested sphere lies on its registered stretch of the ray, which starts later).
             // sphere.cpp:72-99 on geometry s; the sphere's index is only needed when the hit could become the closest one
+#ifdef RTX_WALK_STATS
+            uint32_t ws_roots = 0u;
+#endif
             auto test = [&](const float4 s, auto index) {
                 lane_tests++;
                 const V3    oc = sub(o, mk(s.x, s.y, s.z));
@@ -382,6 +393,9 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 const float cq = dot(oc, oc) - (s.w * s.w);
                 const float disc = bq * bq - a * cq;
                 if (disc > 0) {
+#ifdef RTX_WALK_STATS
+                    ws_roots++;
+#endif
                     const float sq = sqrtf(disc);
                     float       t  = (-bq - sq) / a;
                     if (!(t > 0.001f)) t = (-bq + sq) / a;
@@ -395,6 +409,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 const uint32_t i = P.grid_big[k];
                 if (tracing) test(P.exact[i], [&] { return i; });
             }
+            RTX_STAMP(8);      // (grid: the big list)
             bool scan_all = false;
             if (P.grid.dim[0] != 0u) {
                 const float inf = __builtin_inff();
@@ -463,21 +478,62 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 // box's exit or the hit already found on the big list (the ground), whichever is nearer -- one decision per ray
                 // instead of one per cell (the outermost tier is valid wherever the origin passed the test above).
                 const float s_max = fminf(t_out, closest + slack_t) * (__builtin_amdgcn_sqrtf(a) * 1.00001f);     // as a distance, rounded up
-                const bool  tier1 = !(s_max <= P.grid.tier_s[0]), tier2 = !(s_max <= P.grid.tier_s[1]);   // NaN: the widest lists
+                const bool  tier1_fresh = !(s_max <= P.grid.tier_s[0]), tier2_fresh = !(s_max <= P.grid.tier_s[1]);   // NaN: the widest lists
                 uint32_t it = 0u, it_end = 0u;
                 bool     fresh_cell = true;
-                for (;;) {
-                    if (!__ballot(walking)) break;
+                // Lane decoupling: a wave's walk lasts as long as its longest ray's, and most of its trips run for a
+                // handful of rays.  When at most P.walk_park rays are still walking while at least half the wave waits to be shaded, their
+                // state is PARKED in LDS (13 words per lane, wave_lds + 2304 bytes: behind what phase (D)'s cooperative sampling uses), the
+                // wave shades the finished lanes and fetches their next rays, and the parked walks go on beside those in the next
+                // iteration.  o and d of a parked lane stay in its registers: (D) and (E) do not touch it.
+                float* const park = reinterpret_cast<float*>(wave_lds) + 576u + lane;         // word k of this lane at park[64 k]
+                bool tier1 = tier1_fresh, tier2 = tier2_fresh;
+                if (amask != tmask) {
+                    if (st == kWalking) {
+                        tn[0] = park[0];   tn[1] = park[64];  tn[2] = park[128];
+                        dt[0] = park[192]; dt[1] = park[256]; dt[2] = park[320];
+                        rem     = __float_as_uint(park[384]);
+                        cidx    = __float_as_uint(park[448]);
+                        it      = __float_as_uint(park[512]);
+                        it_end  = __float_as_uint(park[576]);
+                        closest = park[640];
+                        best    = __float_as_uint(park[704]);
+                        const uint32_t fl = __float_as_uint(park[768]);
+                        tier1 = (fl & 1u) != 0u; tier2 = (fl & 2u) != 0u; fresh_cell = (fl & 4u) != 0u;
+                        walking = true;
+                    }
+                }
+                // (no parking while the wave drains at the end of the launch: the lanes it would free have nothing to fetch)
+                const uint32_t park_lim = (uint32_t)__popcll(amask) >= 48u ? P.walk_park : 0u;
+                RTX_STAMP(9);  // (grid: clip, cell and tier set-up)
+#ifdef RTX_WALK_STATS
+                uint32_t ws_t = 0u, l_trips = 0u, l_cells = 0u, l_tests = 0u;
+                ws_roots = 0u;
+#endif
+                if (__ballot(walking)) for (;;) {
+#ifdef RTX_WALK_STATS
+                    ws_t++; WS_ADD(2, 1); { const uint64_t m_ = __ballot(walking); WS_ADD(3, __popcll(m_)); }
+                    if (walking) l_trips++;
+                    { const uint64_t m_ = __ballot(walking && fresh_cell); if (m_) { WS_ADD(4, 1); WS_ADD(5, __popcll(m_)); } if (walking && fresh_cell) l_cells++; }
+                    const uint32_t ws_r0 = ws_roots;
+#endif
                     if (walking && fresh_cell) {
                         const uint4 rec = P.grid_cells[cidx];
                         it      = rec.x;
                         it_end  = tier2 ? rec.w : (tier1 ? rec.z : rec.y);
                         fresh_cell = false;
                     }
+#ifdef RTX_WALK_STATS
+                    { const uint64_t m_ = __ballot(walking && it < it_end); if (m_) { WS_ADD(6, 1); WS_ADD(7, __popcll(m_)); } if (walking && it < it_end) l_tests++; }
+#endif
                     if (walking && it < it_end) {
                         test(P.grid_geom[it], [&] { return P.grid_items[it]; });
                         ++it;
                     }
+#ifdef RTX_WALK_STATS
+                    { const uint64_t m_ = __ballot(ws_roots != ws_r0); if (m_) { WS_ADD(10, 1); WS_ADD(11, __popcll(m_)); } }
+                    { const uint64_t m_ = __ballot(walking && it >= it_end); if (m_) { WS_ADD(8, 1); WS_ADD(9, __popcll(m_)); } }
+#endif
                     if (walking && it >= it_end) {
                         // the cell is done: stop if the closest hit lies safely before its exit, else step to the next cell
                         const float t_leave = fminf(tn[0], fminf(tn[1], tn[2]));
@@ -494,7 +550,30 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                             fresh_cell = true;
                         }
                     }
+                    // every trip has served every walking ray (parked ones included: they advance in each iteration); go on while enough of them are left
+                    if ((uint32_t)__popcll(__ballot(walking)) <= park_lim) break;
                 }
+                if (__ballot(walking)) {
+                    if (walking) {          // parked: everything the loop carries (the strides follow from d, the slack from a)
+                        park[0]   = tn[0]; park[64]  = tn[1]; park[128] = tn[2];
+                        park[192] = dt[0]; park[256] = dt[1]; park[320] = dt[2];
+                        park[384] = __uint_as_float(rem);
+                        park[448] = __uint_as_float(cidx);
+                        park[512] = __uint_as_float(it);
+                        park[576] = __uint_as_float(it_end);
+                        park[640] = closest;
+                        park[704] = __uint_as_float(best);
+                        park[768] = __uint_as_float((tier1 ? 1u : 0u) | (tier2 ? 2u : 0u) | (fresh_cell ? 4u : 0u));
+                        st = kWalking;
+                    }
+                }
+                if (!walking && st == kWalking) st = kTrace;       // a parked walk has ended: its ray is shaded with the others
+                RTX_STAMP(2);  // (grid: the walk)
+#ifdef RTX_WALK_STATS
+                WS_ADD(0, 1); WS_ADD(1, __popcll(tmask));
+                WS_HIST(0u, ws_t, lane == 0u); WS_HIST(1u, l_trips, tracing); WS_HIST(2u, l_cells, tracing); WS_HIST(3u, l_tests, tracing);
+                for (uint32_t b_ = 0; b_ < 64u; ++b_) { const uint32_t c_ = (uint32_t)__popcll(__ballot(tracing && (l_trips < 63u ? l_trips : 63u) == b_)); if (lane == b_) ws_lin += c_; }
+#endif
             }
             // rays that outran the grid's registrations (origins many scene diameters away): the reference's own loop
             if (__ballot(scan_all)) {
@@ -729,6 +808,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             }
         }
         RTX_STAMP(3);
+        const bool fin = (st == kTrace);        // rays whose _sceneHit is complete: the lanes that (D) and (E) serve (all of `tracing`, except in the grid variant)
         {
 
             if (VALIDATE) {
@@ -751,17 +831,17 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                         }
                     }
                 }
-                const uint64_t bad = __ballot(tracing && (b2 != best || (b2 != kNoHit && c2 != closest)));
+                const uint64_t bad = __ballot(fin && (b2 != best || (b2 != kNoHit && c2 != closest)));
                 c_filter_miss += (uint32_t)__popcll(bad);
             }
         }
 
         // ---- (D) shade: raytracer.cpp:250-270 + material.cu ------------------------------------------------------
         bool ended = false, absorbed = false, depth_end = false;
-        if (tracing) {
+        if (fin) {
             if (P.primary && bounce == 0) P.primary[(size_t)(s_cur - P.spp_begin) * P.npix + pix] = best;
         }
-        const bool hit = tracing && (best != kNoHit);
+        const bool hit = fin && (best != kNoHit);
         uint32_t   mtype = 0;
         V3         albedo = mk(0, 0, 0), hp = mk(0, 0, 0), hn = mk(0, 0, 0);
         float      blur = 0, ior = 1;
@@ -901,7 +981,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 absorbed = true;
                 if (recursive) thr = mk(0, 0, 0);                         // raytracer.cpp:233-235
             }
-        } else if (tracing) {                                             // _background, raytracer.cpp:276-282
+        } else if (fin) {                                                 // _background, raytracer.cpp:276-282
             V3    unit = dun;
             float t    = 0.5f * (unit.y + 1.0f);
             V3    bg   = add(scale(1.0f - t, mk(1.0f, 1.0f, 1.0f)), scale(t, mk(0.5f, 0.7f, 1.0f)));
@@ -920,7 +1000,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             }
         }
         // early-terminated-path accounting: one ballot + popcount per cause, kept in wave-uniform registers
-        c_miss   += (uint32_t)__popcll(__ballot(tracing && !hit));
+        c_miss   += (uint32_t)__popcll(__ballot(fin && !hit));
         c_absorb += (uint32_t)__popcll(__ballot(absorbed));
         c_depth  += (uint32_t)__popcll(__ballot(depth_end));
 
@@ -957,6 +1037,13 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         for (int off = 32; off > 0; off >>= 1) { const uint32_t o_ = (uint32_t)__shfl_xor((int)best_r, off); best_r = o_ > best_r ? o_ : best_r; }
         const uint64_t who = __ballot(wt_last_rays == best_r);
         if (lane == (uint32_t)__builtin_ctzll(who)) { w[0] = wt_last_t0; w[1] = wt_last_rays; w[2] = wt_last_pix; w[3] = wt_last_len; }
+    }
+#endif
+#ifdef RTX_WALK_STATS
+    if (P.walk_stats) {
+        if (lane < 12u && ws_acc)  atomicAdd(&P.walk_stats[lane], (unsigned long long)ws_acc);
+        if (lane < 36u && ws_hist) atomicAdd(&P.walk_stats[16u + lane], (unsigned long long)ws_hist);
+        if (ws_lin) atomicAdd(&P.walk_stats[64u + lane], (unsigned long long)ws_lin);
     }
 #endif
     // wave totals -> global statistics
@@ -1057,7 +1144,7 @@ size_t trace_lds_bytes(int filter, int table_mode, uint32_t n, uint32_t n_pad, u
     const bool   lds_table = table_mode == kTableLds;
     const size_t table = filter == kFilterGrid ? 0 : (lds_table ? (filter == kFilterMfma ? (size_t)(n_pad_mfma + 32) * 64 : (size_t)n_pad * 16) : (table_mode == kTableStream ? kStreamStageBytes : 0));
     const size_t exact = lds_table ? (size_t)((n + 3u) & ~3u) * 16 : 0;
-    return kChunkTabBytes + table + exact + (size_t)(block / 64) * kWaveLdsBytes;
+    return kChunkTabBytes + table + exact + (size_t)(block / 64) * wave_lds_bytes(filter);
 }
 
 int trace_occupancy(int filter, int table_mode, size_t lds_bytes, uint32_t block)

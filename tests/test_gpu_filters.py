@@ -388,3 +388,40 @@ def test_grid_filter_reproduces_the_far_field_noise(ra, case):
         assert s_g["candidates"] < 0.05 * s_g["sphere_tests"]  # served by the grid ...
     if case == "from_very_far_away":
         assert s_g["candidates"] > 0.3 * s_g["sphere_tests"]   # ... and here by the fallback scan (primary rays; the bounces use the grid)
+
+
+@pytest.mark.parametrize("scene,cols,rows,spp", [("book1", 301, 199, 6), ("glass", 200, 120, 6), ("scaled", 160, 100, 4)])
+def test_parked_grid_walks_change_nothing(ra, oracle, golden_scenes, scene, cols, rows, spp):
+    """Lane decoupling (tuning knob walk_park): the walks of a wave's last rays are parked in LDS while the wave shades the others and
+    go on in the next iteration.  Whatever the threshold -- never, a single ray, the default, half the wave -- every ray still meets
+    the full scan's hit (RTX_FLAG_VALIDATE_FILTER) and the frame equals the oracle's bit for bit; so do the counters."""
+    table = golden_scenes[scene]
+    o_accum, o_primary, o_st = oracle.render(table, oracle.book_camera(cols, rows), rows, cols, 0, spp, 50, 21, want_primary=True)
+    tests = None
+    for park in (0, 1, None, 32):
+        ctx = ra.Context(0)
+        ctx.set_filter(ra.FILTER_GRID)
+        if park is not None:
+            ctx.set_tuning("walk_park", park)
+        ctx.upload_scene(table)
+        ctx.set_camera(ra.book_camera(cols, rows))
+        primary, st = ctx.render(cols, rows, 0, spp, 50, 21, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+        assert st["filter_misses"] == 0, (park, st)
+        accum = ctx.read_accum()
+        primary2, st2 = ctx.render(cols, rows, 0, spp, 50, 21, chunk_spp=spp, want_primary=True)          # the production instantiation
+        assert (primary2 == primary).all() and (bits(ctx.read_accum()) == bits(accum)).all()
+        ctx.close()
+        assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all(), park
+        for k in ("samples", "rays", "term_miss", "term_absorb", "term_depth"):
+            assert st[k] == o_st[k] == st2[k], (park, k)
+        tests = st["candidates"] if tests is None else tests
+        assert st["candidates"] == tests == st2["candidates"]         # the same exact tests, only in another iteration
+
+
+def test_walk_park_knob_is_checked(ra):
+    ctx = ra.Context(0)
+    with pytest.raises(Exception):
+        ctx.set_tuning("walk_park", 33)
+    with pytest.raises(Exception):
+        ctx.set_tuning("walk_park", -1)
+    ctx.close()
