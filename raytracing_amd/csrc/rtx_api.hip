@@ -786,6 +786,24 @@ extern "C" int rtx_debug_order(rtx_ctx* c, uint32_t* cost_host, size_t cost_cap,
     return RTX_OK;
 }
 
+// Diagnostic (tests/ and tools/ only, not declared in rtx.h): counts the operand pairs (blocks x 256 x rounds of them, pseudo-random by
+// seed and mode, see quotient_check_kernel) on which the grid variant's root quotient differs from the IEEE division.
+extern "C" int rtx_debug_quotient_check(rtx_ctx* c, uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t rounds, unsigned long long* pairs, unsigned long long* mismatches)
+{
+    if (!c || !pairs || !mismatches || mode > 2u || blocks == 0u || blocks > 65536u || rounds == 0u || rounds > 65536u) return fail(RTX_ERR_ARG, "rtx_debug_quotient_check: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* bad = nullptr;
+    HIP_TRY(hipMalloc(&bad, sizeof(*bad)));
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(*bad), c->stream);
+    if (e == hipSuccess) { launch_quotient_check(seed, mode, blocks, rounds, bad, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches, bad, sizeof(*bad), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(bad);
+    HIP_TRY(e);
+    *pairs = (unsigned long long)blocks * 256ull * rounds;
+    return RTX_OK;
+}
+
 extern "C" int rtx_last_chunk_plan(rtx_ctx* c, uint32_t* chunk_spp, uint32_t* n_chunks, uint32_t* starts, uint32_t cap)
 {
     if (!c || !chunk_spp || !n_chunks) return fail(RTX_ERR_ARG, "rtx_last_chunk_plan: NULL argument");

@@ -95,6 +95,7 @@ hipError_t launch_trace(const TraceParams& p, int filter, int table_mode, bool v
 int  trace_occupancy(int filter, int table_mode, size_t lds_bytes, uint32_t block);
 size_t trace_lds_bytes(int filter, int table_mode, uint32_t n, uint32_t n_pad, uint32_t n_pad_mfma, uint32_t block);
 void launch_reduce(const float4* partials, float* accum, uint32_t* cost, unsigned long long* cost_total, uint32_t npix, uint32_t nchunks, bool accumulate, hipStream_t stream);
+void launch_quotient_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t rounds, unsigned long long* bad, hipStream_t stream);
 void launch_fill(float* accum, uint32_t n_floats, float value, bool accumulate, hipStream_t stream);
 void launch_resolve(const float* accum, uint32_t* fb, uint32_t cols, uint32_t rows, uint32_t spp_total, uint32_t debug_tile, hipStream_t stream);
 

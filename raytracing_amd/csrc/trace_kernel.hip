@@ -386,6 +386,14 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
 #ifdef RTX_WALK_STATS
             uint32_t ws_roots = 0u;
 #endif
+            // The roots' two divisions by a = d.d: x / a == (float)((double)x * (1.0 / (double)a)) bit for bit -- the exact quotient of two
+            // floats is either a float or at least 2^-49 (relative) away from every rounding boundary of the float format (the boundary's 25-bit
+            // significand times a's 24 bits cannot miss x's by less than one unit), and the double product is within 1.5 * 2^-52 of it; results
+            // that round into the subnormal range may differ, but a root is only ever compared with 0.001 and FLT_MAX.  One double reciprocal
+            // per ray, then convert - multiply - convert per root instead of the 12-instruction IEEE sequence (tests/test_gpu_edges.py checks
+            // the identity on the device over 2^32 operand pairs).
+            const double rd = 1.0 / (double)a;
+            auto quot = [&](float x) { return (float)((double)x * rd); };
             auto test = [&](const float4 s, auto index) {
                 lane_tests++;
                 const V3    oc = sub(o, mk(s.x, s.y, s.z));
@@ -397,8 +405,8 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     ws_roots++;
 #endif
                     const float sq = sqrtf(disc);
-                    float       t  = (-bq - sq) / a;
-                    if (!(t > 0.001f)) t = (-bq + sq) / a;
+                    float       t  = quot(-bq - sq);
+                    if (!(t > 0.001f)) t = quot(-bq + sq);
                     if (t > 0.001f && t < 3.402823466e+38f && t <= closest) {
                         const uint32_t i = index();
                         if (t < closest || i < best) { closest = t; best = i; }
@@ -1097,6 +1105,42 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float4* __restrict__ 
     accum[3 * (size_t)p + 0] = total.x;
     accum[3 * (size_t)p + 1] = total.y;
     accum[3 * (size_t)p + 2] = total.z;
+}
+
+// Diagnostic (rtx_debug_quotient_check, tests/test_gpu_edges.py): the identity behind the grid variant's roots, x / a ==
+// (float)((double)x * (1.0 / (double)a)), on pseudo-random operand pairs.  mode 0: arbitrary bit patterns (NaN, infinities, zeros and
+// subnormals included); mode 1: the kernel's range, a = d.d in [2^-24, 2^24) and |x| in [2^-40, 2^40); mode 2: a and x with few
+// significant bits (quotients close to rounding boundaries).  Results that are NaN on both sides or subnormal / zero on both sides
+// count as equal (a root is only ever compared with 0.001 and FLT_MAX).
+__global__ void __launch_bounds__(256) quotient_check_kernel(uint32_t seed, uint32_t mode, uint32_t rounds, unsigned long long* __restrict__ bad)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t mism = 0u;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t w[4];
+        philox4x32_10(tid, r, seed, mode, 0x9E3779B9u, 0xBB67AE85u, w);
+        uint32_t xb = w[0], ab = w[1];
+        if (mode == 1u) {
+            xb = (w[0] & 0x807FFFFFu) | ((87u + w[2] % 80u) << 23);
+            ab = (w[1] & 0x007FFFFFu) | ((103u + w[3] % 48u) << 23);
+        } else if (mode == 2u) {
+            xb = (w[0] & (0xFFFFFFFFu << (w[2] % 23u))) & 0x807FFFFFu; xb |= (100u + (w[2] >> 8) % 56u) << 23;
+            ab = (w[1] & (0xFFFFFFFFu << (w[3] % 23u))) & 0x007FFFFFu; ab |= (100u + (w[3] >> 8) % 56u) << 23;
+        }
+        const float  x = __uint_as_float(xb), a = __uint_as_float(ab);
+        const float  q1 = x / a;
+        const double rd = 1.0 / (double)a;
+        const float  q2 = (float)((double)x * rd);
+        const bool   same = __float_as_uint(q1) == __float_as_uint(q2) || (q1 != q1 && q2 != q2)
+                         || (__builtin_fabsf(q1) < 1.17549435e-38f && __builtin_fabsf(q2) < 1.17549435e-38f);
+        mism += same ? 0u : 1u;
+    }
+    if (mism) atomicAdd(bad, (unsigned long long)mism);
+}
+
+void launch_quotient_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t rounds, unsigned long long* bad, hipStream_t stream)
+{
+    hipLaunchKernelGGL(quotient_check_kernel, dim3(blocks), dim3(256), 0, stream, seed, mode, rounds, bad);
 }
 
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ accum, uint32_t n, float value, int accumulate)
