@@ -116,7 +116,7 @@ struct rtx_ctx {
     float4*  exact = nullptr;
     uint4*   mat = nullptr;
     GridDesc  grid{};                // RTX_FILTER_GRID: built at upload (rtx_host.cpp, build_grid)
-    uint4* grid_cells = nullptr; float4* grid_geom = nullptr; uint32_t* grid_items = nullptr; uint32_t* grid_big = nullptr;
+    float4* grid_cells = nullptr; float4* grid_recs = nullptr; uint32_t* grid_big = nullptr;
     bool     have_scene = false, have_camera = false;
     rtx_camera cam{};
     // frame
@@ -217,7 +217,7 @@ extern "C" int rtx_destroy(rtx_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (const rtx_ctx::Pinned& p : c->pinned) (void)hipHostFree(p.host);
-    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->grid_cells, c->grid_geom, c->grid_items, c->grid_big, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats,
+    void* bufs[] = { c->hot, c->hot_mfma, c->exact, c->mat, c->grid_cells, c->grid_recs, c->grid_big, c->accum_borrowed ? nullptr : c->accum, c->partials, c->att_stack, c->primary, c->fb, c->work_counter, c->stats,
                      c->cost, c->order, c->sort_keys, c->sort_vals, c->sort_tmp, c->cost_total };
     for (void* b : bufs) if (b) (void)hipFree(b);
     hipEvent_t evs[] = { c->ev_first, c->ev_last, c->ev_t0, c->ev_t1 };
@@ -350,21 +350,36 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
     {
         GridHost G;
         build_grid(n, cx, cy, cz, radius, c->tune.grid_density_pct / 100.0, &G);
-        void* old[] = { c->grid_cells, c->grid_geom, c->grid_items, c->grid_big };
+        void* old[] = { c->grid_cells, c->grid_recs, c->grid_big };
         for (void* b : old) if (b) (void)hipFree(b);
-        c->grid_cells = nullptr; c->grid_geom = nullptr; c->grid_items = c->grid_big = nullptr;
-        // device form: (begin, end of tier 0, 1, 2) per cell in one 16-byte word, and the geometry copied next to every registration
-        std::vector<uint4>  range(G.cell_start.empty() ? 0 : G.cell_start.size() - 1);
-        std::vector<float4> geom(G.items.size());
-        for (size_t k = 0; k < range.size(); ++k) range[k] = make_uint4(G.cell_start[k], G.tier_end[3 * k], G.tier_end[3 * k + 1], G.tier_end[3 * k + 2]);
-        for (size_t k = 0; k < geom.size(); ++k) geom[k] = exact[G.items[k]];
-        HIP_TRY(hipMalloc(&c->grid_cells, std::max<size_t>(range.size(), 1) * sizeof(uint4)));
-        HIP_TRY(hipMalloc(&c->grid_geom, std::max<size_t>(geom.size(), 1) * sizeof(float4)));
-        HIP_TRY(hipMalloc(&c->grid_items, std::max<size_t>(G.items.size(), 1) * sizeof(uint32_t)));
+        c->grid_cells = nullptr; c->grid_recs = nullptr; c->grid_big = nullptr;
+        // Device form, 32 bytes per walk trip: per cell (first entry, index of the first entry's sphere, entries of tier 0 | up to tier 1
+        // << 16, entries up to tier 2) + that sphere's geometry; per entry the geometry of its sphere (a copy) + its index.  The two
+        // 16-bit counts bound a cell's inner tiers at 65 535 entries: a table that exceeds that (tens of thousands of spheres through
+        // one cell) gets no grid -- every sphere goes on the list that each ray tests in full, the reference's own loop.
+        size_t ncells = G.cell_start.empty() ? 0 : G.cell_start.size() - 1;
+        for (size_t k = 0; k < ncells; ++k)
+            if (G.tier_end[3 * k + 1] - G.cell_start[k] > 0xFFFFu) { ncells = 0; break; }
+        if (ncells == 0 && G.desc.dim[0] != 0u) {
+            G.desc.dim[0] = G.desc.dim[1] = G.desc.dim[2] = 0u;
+            G.big.resize(n);
+            for (uint32_t i = 0; i < n; ++i) G.big[i] = i;
+            G.desc.n_big = n;
+            G.items.clear();
+        }
+        auto asf = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+        std::vector<float4> cells(2 * ncells), recs(2 * G.items.size());
+        for (size_t k = 0; k < ncells; ++k) {
+            const uint32_t b = G.cell_start[k], e0 = G.tier_end[3 * k] - b, e1 = G.tier_end[3 * k + 1] - b, e2 = G.tier_end[3 * k + 2] - b;
+            cells[2 * k]     = make_float4(asf(b), asf(e2 ? G.items[b] : 0u), asf(e0 | (e1 << 16)), asf(e2));
+            cells[2 * k + 1] = e2 ? exact[G.items[b]] : make_float4(0, 0, 0, 0);
+        }
+        for (size_t k = 0; k < G.items.size(); ++k) { recs[2 * k] = exact[G.items[k]]; recs[2 * k + 1] = make_float4(asf(G.items[k]), 0, 0, 0); }
+        HIP_TRY(hipMalloc(&c->grid_cells, std::max<size_t>(cells.size(), 2) * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->grid_recs, std::max<size_t>(recs.size(), 2) * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->grid_big, std::max<size_t>(G.big.size(), 1) * sizeof(uint32_t)));
-        if (!range.empty()) HIP_TRY(hipMemcpy(c->grid_cells, range.data(), range.size() * sizeof(uint4), hipMemcpyHostToDevice));
-        if (!geom.empty()) HIP_TRY(hipMemcpy(c->grid_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
-        if (!G.items.empty()) HIP_TRY(hipMemcpy(c->grid_items, G.items.data(), G.items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!cells.empty()) HIP_TRY(hipMemcpy(c->grid_cells, cells.data(), cells.size() * sizeof(float4), hipMemcpyHostToDevice));
+        if (!recs.empty()) HIP_TRY(hipMemcpy(c->grid_recs, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
         if (!G.big.empty()) HIP_TRY(hipMemcpy(c->grid_big, G.big.data(), G.big.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->grid = G.desc;
     }
@@ -579,7 +594,7 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
     if (c->tune.wave_batch) wave_batch = (uint32_t)c->tune.wave_batch;
     if ((uint64_t)R.n_items + (uint64_t)R.lp.max_grid * (R.lp.block / 64u) * 2u * wave_batch >= (1ull << 32)) return fail(RTX_ERR_ARG, "%s: work counter would overflow; raise chunk_spp", who);
 
-    P.grid = c->grid; P.grid_cells = c->grid_cells; P.grid_geom = c->grid_geom; P.grid_items = c->grid_items; P.grid_big = c->grid_big;
+    P.grid = c->grid; P.grid_cells = c->grid_cells; P.grid_recs = c->grid_recs; P.grid_big = c->grid_big;
     P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.mfma_scale = c->mfma_scale; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
     P.cols = cols; P.rows = rows; P.npix = R.npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = R.nchunks;
     P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = R.n_items; P.wave_batch = wave_batch;
@@ -790,7 +805,7 @@ extern "C" int rtx_debug_order(rtx_ctx* c, uint32_t* cost_host, size_t cost_cap,
 // seed and mode, see quotient_check_kernel) on which the grid variant's root quotient differs from the IEEE division.
 extern "C" int rtx_debug_quotient_check(rtx_ctx* c, uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t rounds, unsigned long long* pairs, unsigned long long* mismatches)
 {
-    if (!c || !pairs || !mismatches || mode > 2u || blocks == 0u || blocks > 65536u || rounds == 0u || rounds > 65536u) return fail(RTX_ERR_ARG, "rtx_debug_quotient_check: bad argument");
+    if (!c || !pairs || !mismatches || mode > 3u || blocks == 0u || blocks > 65536u || rounds == 0u || rounds > 65536u) return fail(RTX_ERR_ARG, "rtx_debug_quotient_check: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long* bad = nullptr;
     HIP_TRY(hipMalloc(&bad, sizeof(*bad)));

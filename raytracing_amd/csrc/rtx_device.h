@@ -59,10 +59,9 @@ struct TraceParams {
     const float4* hot_mfma; // (n_pad_mfma/32 + 1) tiles x 2 MFMAs x 64 lanes x 16 B: f16 A operands (ten monomials per sphere) of the MFMA filter
     uint32_t      n_pad_mfma;
     float         mfma_scale; // power of two applied to the sphere side of the MFMA filter (f16 range)
-    GridDesc      grid;       // RTX_FILTER_GRID: uniform grid over the table (rtx_plan.h); cell c holds the entries [grid_cells[c].x, grid_cells[c].w) of grid_geom (centre, radius: a copy, so that a test is one load behind the cell's) / grid_items (sphere index); .y, .z, .w end the registration tiers 0, 1, 2
-    const uint4*    grid_cells;
-    const float4*   grid_geom;
-    const uint32_t* grid_items;
+    GridDesc      grid;       // RTX_FILTER_GRID: uniform grid over the table (rtx_plan.h); a cell's entries are stored tier by tier; the walk reads one 32-byte record per trip
+    const float4*   grid_cells;  // 2 per cell: (first entry, index of its sphere, entries of tier 0 | up to tier 1 << 16, entries up to tier 2), (that sphere's cx, cy, cz, r)
+    const float4*   grid_recs;   // 2 per entry: (cx, cy, cz, r) of the registered sphere -- a copy, so that a test is one fetch --, (its index, -, -, -)
     const uint32_t* grid_big;  // grid.n_big spheres tested for every ray
     const float4* exact;    // n x (cx, cy, cz, r)                   -- sphere.h:24-28 geometry, as uploaded
     const uint4*  mat;      // 2n: [2i] = (type, albedo r, g, b), [2i+1] = (blur, ior, 0, 0), float bits

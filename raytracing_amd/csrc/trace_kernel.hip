@@ -89,6 +89,22 @@ __device__ __forceinline__ uint32_t rank_in(uint64_t mask)
 }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// sqrtf(x), correctly rounded, in 9 instructions instead of the compiler's 21.  The compiler's expansion is v_sqrt_f32 (1 ulp), the two
+// neighbours y -/+ 1 ulp, two fused residuals that pick among the three -- and, around that, a rescaling of arguments below 2^-96 (whose
+// residuals would underflow) and a class test for 0 / inf.  This is the same selection without the wrapping; when any lane's argument is
+// outside [2^-96, inf) (a NaN included) the whole wave takes the compiler's sqrtf.  Identical results by construction; the device checks
+// it for every one of the 2^32 bit patterns (rtx_debug_quotient_check mode 3, tests/test_gpu_edges.py).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    if (__ballot(!(x >= 1.262177448e-29f && x < __builtin_inff()))) return sqrtf(x);
+    const float y  = __builtin_amdgcn_sqrtf(x);
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);
+    float r = (0.0f >= rm) ? ym : y;
+    r = (0.0f < rp) ? yp : r;
+    return r;
+}
+
 // Diagnostic build only (-DRTX_PHASE_TIMERS): per-phase wave cycles, s_memtime deltas summed into stats[kStCount + slot].
 #ifdef RTX_PHASE_TIMERS
 #define RTX_STAMP(slot) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph[slot] += now_ - ph_last; ph_last = now_; } while (0)
@@ -125,8 +141,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+#ifndef RTX_GRID_WAVES
+#define RTX_GRID_WAVES 6
+#endif
 template <int FILTER, int TABLE, bool VALIDATE>
-__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(FILTER == kFilterGrid ? 6 : 4))) trace_kernel(const TraceParams P)   // <= 128 VGPRs; the grid walk hides its dependent loads better with 6 waves of <= 80 (36.6 -> 32.3 ms at 20 164 spheres; 8 waves spill)
+__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(FILTER == kFilterGrid ? RTX_GRID_WAVES : 4))) trace_kernel(const TraceParams P)   // <= 128 VGPRs; the grid walk hides its dependent loads better with 6 waves of <= 80 (36.6 -> 32.3 ms at 20 164 spheres; 8 waves spill)
 {
     constexpr bool LDS_TABLE = (TABLE == kTableLds);
     constexpr bool STREAM    = (TABLE == kTableStream);
@@ -394,28 +413,29 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             // the identity on the device over 2^32 operand pairs).
             const double rd = 1.0 / (double)a;
             auto quot = [&](float x) { return (float)((double)x * rd); };
-            auto test = [&](const float4 s, auto index) {
-                lane_tests++;
+            // (written with selects: the walk loop is bound by the instructions it issues, scalar ones -- the lane masks of nested
+            // conditions -- included; the one branch left skips the roots when no lane's discriminant is positive)
+            auto test = [&](const bool active, const float4 s, const uint32_t i) {
+                lane_tests += active ? 1u : 0u;
                 const V3    oc = sub(o, mk(s.x, s.y, s.z));
                 const float bq = dot(oc, d);
                 const float cq = dot(oc, oc) - (s.w * s.w);
                 const float disc = bq * bq - a * cq;
-                if (disc > 0) {
+                if (active && disc > 0) {
 #ifdef RTX_WALK_STATS
                     ws_roots++;
 #endif
-                    const float sq = sqrtf(disc);
+                    const float sq = sqrt_rn(disc);
                     float       t  = quot(-bq - sq);
                     if (!(t > 0.001f)) t = quot(-bq + sq);
-                    if (t > 0.001f && t < 3.402823466e+38f && t <= closest) {
-                        const uint32_t i = index();
-                        if (t < closest || i < best) { closest = t; best = i; }
-                    }
+                    const bool take = t > 0.001f && t < 3.402823466e+38f && (t < closest || (t == closest && i < best));
+                    closest = take ? t : closest;
+                    best    = take ? i : best;
                 }
             };
             for (uint32_t k = 0; k < P.grid.n_big; ++k) {
                 const uint32_t i = P.grid_big[k];
-                if (tracing) test(P.exact[i], [&] { return i; });
+                test(tracing, P.exact[i], i);
             }
             RTX_STAMP(8);      // (grid: the big list)
             bool scan_all = false;
@@ -525,38 +545,61 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     { const uint64_t m_ = __ballot(walking && fresh_cell); if (m_) { WS_ADD(4, 1); WS_ADD(5, __popcll(m_)); } if (walking && fresh_cell) l_cells++; }
                     const uint32_t ws_r0 = ws_roots;
 #endif
-                    if (walking && fresh_cell) {
-                        const uint4 rec = P.grid_cells[cidx];
-                        it      = rec.x;
-                        it_end  = tier2 ? rec.w : (tier1 ? rec.z : rec.y);
-                        fresh_cell = false;
+                    // One fetch of 32 bytes per walking ray and trip, one wait: the record of the cell just entered -- (first entry, its sphere's
+                    // index, entries per tier, that sphere's geometry) -- or the next entry of the cell the ray is in (geometry, index).
+                    float4 ra, rb;
+                    if (walking) {
+                        const float4* const p = fresh_cell ? P.grid_cells + 2u * (size_t)cidx : P.grid_recs + 2u * (size_t)it;
+                        ra = p[0];
+                        rb = p[1];
                     }
-#ifdef RTX_WALK_STATS
-                    { const uint64_t m_ = __ballot(walking && it < it_end); if (m_) { WS_ADD(6, 1); WS_ADD(7, __popcll(m_)); } if (walking && it < it_end) l_tests++; }
+#ifdef RTX_PROBE_VALU      // diagnostic: what do RTX_PROBE_VALU more vector instructions per trip cost?
+                    { float pv = ra.x;
+#pragma unroll
+                      for (int k_ = 0; k_ < RTX_PROBE_VALU; ++k_) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pv));
+                      asm volatile("" :: "v"(pv)); }
 #endif
-                    if (walking && it < it_end) {
-                        test(P.grid_geom[it], [&] { return P.grid_items[it]; });
-                        ++it;
-                    }
+#ifdef RTX_PROBE_SALU      // diagnostic: ... scalar instructions
+                    { uint32_t ps = 1u;
+#pragma unroll
+                      for (int k_ = 0; k_ < RTX_PROBE_SALU; ++k_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps) :: "scc");
+                      asm volatile("" :: "s"(ps)); }
+#endif
+#ifdef RTX_PROBE_LOAD      // diagnostic: ... one more dependent fetch
+                    if (walking) { const float4 x_ = P.grid_cells[__float_as_uint(ra.x) & 1u]; asm volatile("s_waitcnt vmcnt(0)" :: "v"(x_.x) : "memory"); }
+#endif
+                    const uint32_t cnts = __float_as_uint(ra.z);
+                    const uint32_t cnt  = tier2 ? __float_as_uint(ra.w) : (tier1 ? cnts >> 16 : (cnts & 0xFFFFu));
+                    const uint32_t idx  = __float_as_uint(fresh_cell ? ra.y : rb.x);
+                    const float4   geo  = fresh_cell ? rb : ra;
+                    const bool     entered = walking && fresh_cell;
+                    it     = entered ? __float_as_uint(ra.x) : it;
+                    it_end = entered ? it + cnt : it_end;
+                    const bool has = walking && it < it_end;
+#ifdef RTX_WALK_STATS
+                    { const uint64_t m_ = __ballot(has); if (m_) { WS_ADD(6, 1); WS_ADD(7, __popcll(m_)); } if (has) l_tests++; }
+#endif
+                    test(has, geo, idx);
+                    it += has ? 1u : 0u;
 #ifdef RTX_WALK_STATS
                     { const uint64_t m_ = __ballot(ws_roots != ws_r0); if (m_) { WS_ADD(10, 1); WS_ADD(11, __popcll(m_)); } }
                     { const uint64_t m_ = __ballot(walking && it >= it_end); if (m_) { WS_ADD(8, 1); WS_ADD(9, __popcll(m_)); } }
 #endif
-                    if (walking && it >= it_end) {
-                        // the cell is done: stop if the closest hit lies safely before its exit, else step to the next cell
+                    // a ray whose cell is done stops if its closest hit lies safely before the cell's exit (or the box ends), else steps to the next cell
+                    {
+                        const bool  done = walking && it >= it_end;
                         const float t_leave = fminf(tn[0], fminf(tn[1], tn[2]));
                         const bool  ax0 = tn[0] <= tn[1] && tn[0] <= tn[2], ax1 = !ax0 && tn[1] <= tn[2];
                         const uint32_t sh = ax0 ? 0u : (ax1 ? 10u : 20u);
-                        if (closest + slack_t + closest * 4.0e-6f < t_leave || ((rem >> sh) & 1023u) == 0u) {
-                            walking = false;
-                        } else {
-                            rem  -= 1u << sh;
-                            cidx += (uint32_t)(ax0 ? cstride[0] : (ax1 ? cstride[1] : cstride[2]));
-                            tn[0] += ax0 ? dt[0] : 0.0f;
-                            tn[1] += ax1 ? dt[1] : 0.0f;
-                            tn[2] += (ax0 || ax1) ? 0.0f : dt[2];
-                            fresh_cell = true;
-                        }
+                        const bool  stop = closest + slack_t + closest * 4.0e-6f < t_leave || ((rem >> sh) & 1023u) == 0u;
+                        const bool  adv  = done && !stop;
+                        walking = walking && !(done && stop);
+                        rem  -= adv ? (1u << sh) : 0u;
+                        cidx += adv ? (uint32_t)(ax0 ? cstride[0] : (ax1 ? cstride[1] : cstride[2])) : 0u;
+                        tn[0] += (adv && ax0) ? dt[0] : 0.0f;
+                        tn[1] += (adv && ax1) ? dt[1] : 0.0f;
+                        tn[2] += (adv && !ax0 && !ax1) ? dt[2] : 0.0f;
+                        fresh_cell = adv;
                     }
                     // every trip has served every walking ray (parked ones included: they advance in each iteration); go on while enough of them are left
                     if ((uint32_t)__popcll(__ballot(walking)) <= park_lim) break;
@@ -587,7 +630,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             if (__ballot(scan_all)) {
                 for (uint32_t i = 0; i < P.n; ++i) {
                     const float4 s = P.exact[i];
-                    if (scan_all) test(s, [&] { return i; });
+                    test(scan_all, s, i);
                 }
             }
         } else {
@@ -619,7 +662,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     const float cq = dot(oc, oc) - (s.w * s.w);
                     const float disc = bq * bq - ra * cq;
                     if (disc > 0 && i < P.n) {            // i >= n: a padded row, flagged only by a NaN / Inf ray (the reference finds no hit for one)
-                        const float sq = sqrtf(disc);
+                        const float sq = sqrt_rn(disc);
                         float       t  = (-bq - sq) / ra;
                         if (!(t > 0.001f)) t = (-bq + sq) / ra;
                         if (t > 0.001f && t < 3.402823466e+38f)    // sphere.cpp:81,90: t < max, and max starts at FLT_MAX
@@ -919,7 +962,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         RTX_STAMP(5);
         // |d| and d / |d| once per ray: the metal and glass branches and the background all use them (material.cu:60,
         // :83-88, :120; raytracer.cpp:278), and in lockstep every branch that any lane takes is paid for by all
-        const float dlen = sqrtf(a);                                       // a = d.d in the order of vector_cuda.h:41
+        const float dlen = sqrt_rn(a);                                      // a = d.d in the order of vector_cuda.h:41
         const V3    dun  = mk(d.x / dlen, d.y / dlen, d.z / dlen);         // vector_cuda.h:45-59
         if (hit) {
             V3   att = albedo, nd_ = d;
@@ -953,7 +996,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 V3    refracted = mk(0, 0, 0);
                 float prob;
                 if (disc > 0) {
-                    refracted = sub(scale(ni, sub(uv, scale(dt, outward))), scale(sqrtf(disc), outward));
+                    refracted = sub(scale(ni, sub(uv, scale(dt, outward))), scale(sqrt_rn(disc), outward));
                     // _schlick, material.cu:132-138: pow(float,int) promotes to double
                     float  r0 = (1.0f - ior) / (1.0f + ior);
                     r0        = r0 * r0;
@@ -1126,6 +1169,12 @@ __global__ void __launch_bounds__(256) quotient_check_kernel(uint32_t seed, uint
         } else if (mode == 2u) {
             xb = (w[0] & (0xFFFFFFFFu << (w[2] % 23u))) & 0x807FFFFFu; xb |= (100u + (w[2] >> 8) % 56u) << 23;
             ab = (w[1] & (0xFFFFFFFFu << (w[3] % 23u))) & 0x007FFFFFu; ab |= (100u + (w[3] >> 8) % 56u) << 23;
+        }
+        if (mode == 3u) {          // sqrt_rn against sqrtf on bit pattern tid * rounds + r: all 2^32 of them for blocks x 256 x rounds = 2^32
+            const float v = __uint_as_float(tid * rounds + r);
+            const float s1 = sqrtf(v), s2 = sqrt_rn(v);
+            mism += (__float_as_uint(s1) == __float_as_uint(s2) || (s1 != s1 && s2 != s2)) ? 0u : 1u;
+            continue;
         }
         const float  x = __uint_as_float(xb), a = __uint_as_float(ab);
         const float  q1 = x / a;

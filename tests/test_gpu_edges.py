@@ -400,13 +400,14 @@ def test_resolve_into_pinned_host_memory(ra, ctx, golden_scenes):
     assert ra.lib().rtx_host_alloc(ctx._h, 0, None) == -1               # RTX_ERR_ARG
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_root_quotient_identity_on_the_device(ra, mode):
     """The grid variant divides its roots by a = d.d as (float)((double)x * (1.0 / (double)a)) (trace_kernel.hip, `quot`): one double
     reciprocal per ray instead of an IEEE division per root.  The identity with x / a is argued in the kernel's comment; here the
     device checks it on 2^32 operand pairs per mode -- arbitrary bit patterns, the kernel's own range, operands with few significant
     bits (quotients near rounding boundaries) -- counting every pair whose two quotients differ in a bit (NaN on both sides and
-    subnormal results on both sides aside: a root is only compared with 0.001 and FLT_MAX)."""
+    subnormal results on both sides aside: a root is only compared with 0.001 and FLT_MAX).  Mode 3: the kernel's 9-instruction
+    square root (sqrt_rn) against the compiler's sqrtf on every one of the 2^32 bit patterns."""
     import ctypes as C
     L = ra.lib()
     L.rtx_debug_quotient_check.restype = C.c_int
