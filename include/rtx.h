@@ -126,6 +126,8 @@ int rtx_set_filter(rtx_ctx* ctx, int kind);
  *   "order_chunks"   RTX_ORDER_CHUNKS    most sample chunks of such a launch (16)
  *   "order_share_pct" RTX_ORDER_SHARE_PCT share of such a launch's expected duration that its longest work item may take (50)
  *   "tail_guard"     RTX_TAIL_GUARD      the last tail_guard x resident lanes work items are reserved on demand, not ahead (4)
+ *   "walk_park"      RTX_WALK_PARK       grid filter: the walks of a wave's last walk_park rays are parked in LDS while the wave shades
+ *                                        the others, and go on in the next iteration (10; 0: every walk ends in its own iteration; at most 32)
  *   "print_phases"   RTX_PRINT_PHASES    diagnostic builds only */
 int rtx_set_tuning(rtx_ctx* ctx, const char* key, int value);
 
