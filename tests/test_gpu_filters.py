@@ -425,3 +425,34 @@ def test_walk_park_knob_is_checked(ra):
     with pytest.raises(Exception):
         ctx.set_tuning("walk_park", -1)
     ctx.close()
+
+
+def test_grid_cell_with_more_entries_than_its_record_counts(ra, oracle):
+    """A grid cell's record counts the entries of its two inner tiers in 16 bits.  A table that puts more spheres than that through
+    one cell (here 66 000 specks in a cluster a fifth of a cell wide, in a field of 1 500 spread spheres) gets no grid: every
+    sphere goes on the list that each ray tests in full -- the reference's own loop -- and the image still equals the oracle's."""
+    rng = np.random.default_rng(5)
+    n_cluster, n_field = 66000, 1500
+    t = np.zeros((n_cluster + n_field + 1, 10), dtype=np.float32)
+    t[0, 0:4] = (0, -1000, 0, 1000)
+    t[1:1 + n_field, 0] = rng.uniform(-20, 20, n_field); t[1:1 + n_field, 1] = 0.2; t[1:1 + n_field, 2] = rng.uniform(-20, 20, n_field)
+    t[1:1 + n_field, 3] = 0.2
+    t[1 + n_field:, 0:3] = np.array([1.0, 0.3, 0.5], dtype=np.float32) + rng.uniform(-0.05, 0.05, size=(n_cluster, 3)).astype(np.float32)
+    t[1 + n_field:, 3] = 0.01
+    t[:, 4] = 1; t[:, 5:8] = 0.6; t[:, 8] = 0; t[:, 9] = 1
+    cols, rows, spp = 40, 24, 1
+    args = (5.0, np.float32(cols) / np.float32(rows), 0.0, 10.0, np.array([6, 2, 3], dtype=np.float32), (0, 1, 0), (1, 0.3, 0.5))
+    ctx = ra.Context(0)
+    try:
+        ctx.set_filter(ra.FILTER_GRID)
+        ctx.upload_scene(t)
+        ctx.set_camera(ra.Camera(*args))
+        primary, st = ctx.render(cols, rows, 0, spp, 8, 4, flags=ra.FLAG_VALIDATE_FILTER, chunk_spp=spp, want_primary=True)
+        accum = ctx.read_accum()
+    finally:
+        ctx.close()
+    assert st["filter_misses"] == 0
+    assert st["candidates"] == st["rays"] * len(t)                   # no grid: every ray met every sphere
+    o_accum, o_primary, o_st = oracle.render(t, oracle.camera(*args), rows, cols, 0, spp, 8, 4, want_primary=True)
+    assert (primary == o_primary).all() and (bits(accum) == bits(o_accum)).all() and st["rays"] == o_st["rays"]
+    assert (primary >= 1 + n_field).any()                           # the cluster is in the picture
