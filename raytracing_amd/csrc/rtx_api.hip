@@ -3,7 +3,8 @@
 #include "rtx_device.h"
 
 #include <cstring>
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library itself is loaded when a group needs it (rccl_load)
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
@@ -1249,10 +1250,49 @@ static __global__ void __launch_bounds__(256) accum_add_kernel(float* __restrict
     if (i < n) dst[i] = dst[i] + src[i];
 }
 
+// RCCL is resolved when the first group that needs it is created (dlopen + dlsym), so that a process that renders on one GPU -- the
+// common case -- neither loads librccl.so nor pays its start-up.  The seven entry points the exchange uses:
+struct RcclApi {
+    void* lib = nullptr;
+    const char*  (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;
+
+static int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return RTX_OK;
+    const char* names[] = { getenv("RTX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    void* lib = nullptr;
+    for (const char* nm : names) if (nm && *nm && (lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return fail(RTX_ERR_DEVICE, "a group of several GPUs needs RCCL: librccl.so could not be loaded (%s); set RTX_RCCL_LIB to its path", dlerror());
+    RcclApi a;
+    a.lib = lib;
+    bool ok = true;
+    auto sym = [&](const char* nm) { void* p = dlsym(lib, nm); if (!p) ok = false; return p; };
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.CommInitAll    = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+    a.CommDestroy    = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.GroupStart     = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd       = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.AllReduce      = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.Reduce         = reinterpret_cast<decltype(a.Reduce)>(sym("ncclReduce"));
+    if (!ok) { dlclose(lib); return fail(RTX_ERR_DEVICE, "librccl.so lacks one of the entry points the exchange uses"); }
+    g_rccl = a;
+    return RTX_OK;
+}
+
 #define NCCL_TRY(expr)                                                                                         \
     do {                                                                                                       \
         ncclResult_t r_ = (expr);                                                                              \
-        if (r_ != ncclSuccess) return fail(RTX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+        if (r_ != ncclSuccess) return fail(RTX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
 // Contiguous share of [spp_begin, spp_begin + spp_count) for member `rank` of `world`; remainder samples go to the lowest
@@ -1271,7 +1311,7 @@ extern "C" int rtx_group_destroy(rtx_group* g)
     for (auto& w : g->workers) w->stop();
     for (size_t i = 0; i < g->comms.size(); ++i) {
         if (g->members[i]) (void)hipSetDevice(g->members[i]->device);
-        if (g->comms[i]) (void)ncclCommDestroy(g->comms[i]);
+        if (g->comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comms[i]);
     }
     if (!g->members.empty() && g->members[0]) (void)hipSetDevice(g->members[0]->device);
     if (g->ex0) (void)hipEventDestroy(g->ex0);
@@ -1313,12 +1353,14 @@ extern "C" int rtx_group_create(const int* device_ids, int n_devices, rtx_group*
     // exchange on a single-GPU box; without it a group of one never touches RCCL
     const char* force = getenv("RTX_GROUP_RCCL");
     if (!loopback && (n_devices > 1 || (force && atoi(force) != 0))) {
+        const int lrc = rccl_load();
+        if (lrc) { rtx_group_destroy(g); return lrc; }
         g->comms.assign((size_t)n_devices, nullptr);
-        const ncclResult_t r = ncclCommInitAll(g->comms.data(), n_devices, device_ids);
+        const ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), n_devices, device_ids);
         if (r != ncclSuccess) {
             g->comms.clear();
             rtx_group_destroy(g);
-            return fail(RTX_ERR_DEVICE, "rtx_group_create: ncclCommInitAll over %d devices failed: %s", n_devices, ncclGetErrorString(r));
+            return fail(RTX_ERR_DEVICE, "rtx_group_create: ncclCommInitAll over %d devices failed: %s", n_devices, g_rccl.GetErrorString(r));
         }
     }
     if (hipSetDevice(g->members[0]->device) != hipSuccess || hipEventCreate(&g->ex0) != hipSuccess || hipEventCreate(&g->ex1) != hipSuccess) {
@@ -1471,14 +1513,14 @@ static int group_enqueue_exchange(rtx_group* g)
     const char* how = getenv("RTX_GROUP_EXCHANGE");
     const bool  to_root = how && strcmp(how, "reduce") == 0;
     HIP_TRY(hipEventRecord(g->ex0, c0->stream));
-    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(g_rccl.GroupStart());
     for (size_t i = 0; i < world; ++i) {
         rtx_ctx* c = g->members[i];
-        const ncclResult_t r = to_root ? ncclReduce(c->accum, c->accum, count, ncclFloat32, ncclSum, 0, g->comms[i], c->stream)
-                                       : ncclAllReduce(c->accum, c->accum, count, ncclFloat32, ncclSum, g->comms[i], c->stream);
-        if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(RTX_ERR_DEVICE, "the RCCL exchange on member %zu failed: %s", i, ncclGetErrorString(r)); }
+        const ncclResult_t r = to_root ? g_rccl.Reduce(c->accum, c->accum, count, ncclFloat32, ncclSum, 0, g->comms[i], c->stream)
+                                       : g_rccl.AllReduce(c->accum, c->accum, count, ncclFloat32, ncclSum, g->comms[i], c->stream);
+        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RTX_ERR_DEVICE, "the RCCL exchange on member %zu failed: %s", i, g_rccl.GetErrorString(r)); }
     }
-    NCCL_TRY(ncclGroupEnd());
+    NCCL_TRY(g_rccl.GroupEnd());
     HIP_TRY(hipSetDevice(c0->device));
     HIP_TRY(hipEventRecord(g->ex1, c0->stream));
     g->ex_timed = true;

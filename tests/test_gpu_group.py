@@ -78,6 +78,7 @@ table = np.load(%r)["book1"]
 cols, rows, spp = 120, 80, 6
 ctx = ra.Context(0); ctx.upload_scene(table); ctx.set_camera(ra.book_camera(cols, rows))
 ctx.render(cols, rows, 0, spp, 50, 3); want = ctx.read_accum(); ctx.close()
+assert "rccl" not in open("/proc/self/maps").read()        # rendering on one GPU has not loaded RCCL
 g = ra.Group([0]); g.upload_scene(table); g.set_camera(ra.book_camera(cols, rows))
 g.render(cols, rows, 0, spp, 50, 3); g.allreduce(); g.allreduce()
 got = g.member(0).read_accum()

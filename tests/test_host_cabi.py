@@ -201,13 +201,19 @@ def test_spp_range_of_the_library_equals_the_python_hosts():
         assert sum(c for _, c in lib_parts) == spp
 
 
-def test_library_imports_rccl():
-    """The multi-device exchange lives under the C ABI: librtx.so itself imports ncclCommInitAll / ncclAllReduce."""
+def test_library_resolves_rccl_when_a_group_needs_it():
+    """The multi-device exchange lives under the C ABI, but a process that renders on one GPU must not pay for RCCL: librtx.so has no
+    link-time dependency on librccl and resolves the seven entry points it uses (dlsym) when the first group of several GPUs is made."""
     import subprocess
     from conftest import ROOT
-    out = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "raytracing_amd", "librtx.so")], text=True)
-    for sym in ("ncclAllReduce", "ncclCommInitAll", "ncclGroupStart", "ncclGroupEnd"):
-        assert (" U " + sym) in out, sym
+    lib = os.path.join(ROOT, "raytracing_amd", "librtx.so")
+    out = subprocess.check_output(["nm", "-D", lib], text=True)
+    assert " U nccl" not in out
+    needed = subprocess.check_output(["readelf", "-d", lib], text=True)
+    assert "rccl" not in needed
+    blob = open(lib, "rb").read()
+    for sym in (b"ncclAllReduce", b"ncclReduce", b"ncclCommInitAll", b"ncclCommDestroy", b"ncclGroupStart", b"ncclGroupEnd", b"ncclGetErrorString"):
+        assert sym + b"\0" in blob, sym
 
 
 def _grid_cells_of(g, lo, hi):
