@@ -250,8 +250,19 @@ extern "C" int rtx_upload_scene(rtx_ctx* c, uint32_t n, const float* cx, const f
             exact[i] = make_float4(cx[i], cy[i], cz[i], radius[i]);
             uint32_t w[6];
             memcpy(&w[0], &ar[i], 4); memcpy(&w[1], &ag[i], 4); memcpy(&w[2], &ab[i], 4); memcpy(&w[3], &blur[i], 4); memcpy(&w[4], &ior[i], 4);
+            if (mat_type[i] == RTX_MATERIAL_GLASS) {
+                // what the glass branch would divide for on every hit, divided once here with the same float operations
+                // (material.cu:87, :133-134); its albedo and blur are never read (attenuation (1, 1, 1), no fuzz)
+                const float inv_ior = 1.0f / ior[i];
+                float       r0      = (1.0f - ior[i]) / (1.0f + ior[i]);
+                r0                  = r0 * r0;
+                memcpy(&w[0], &r0, 4); memcpy(&w[3], &inv_ior, 4);
+            }
+            const double rdr = 1.0 / (double)radius[i];               // the hit normal's divisions by the radius (sphere.cpp:84), see trace_kernel.hip
+            uint32_t rw[2];
+            memcpy(rw, &rdr, 8);
             mat[2 * i]     = make_uint4(mat_type[i], w[0], w[1], w[2]);
-            mat[2 * i + 1] = make_uint4(w[3], w[4], 0u, 0u);
+            mat[2 * i + 1] = make_uint4(w[3], w[4], rw[0], rw[1]);
         } else {
             hot[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0e30f);   // padding: never a candidate
         }
@@ -597,7 +608,7 @@ static int setup_render(rtx_ctx* c, const char* who, uint32_t cols, uint32_t row
 
     P.grid = c->grid; P.grid_cells = c->grid_cells; P.grid_recs = c->grid_recs; P.grid_big = c->grid_big;
     P.hot = c->hot; P.hot_mfma = c->hot_mfma; P.n_pad_mfma = c->n_pad_mfma; P.mfma_scale = c->mfma_scale; P.exact = c->exact; P.mat = c->mat; P.n = c->n; P.n_pad = c->n_pad; P.cam = c->cam;
-    P.cols = cols; P.rows = rows; P.npix = R.npix; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = R.nchunks;
+    P.cols = cols; P.rows = rows; P.npix = R.npix; P.inv_cols = 1.0 / (double)(float)cols; P.inv_rows = 1.0 / (double)(float)rows; P.spp_begin = spp_begin; P.spp_count = spp_count; P.chunk_spp = chunk_spp; P.nchunks = R.nchunks;
     P.max_depth = max_depth; P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.flags = flags; P.n_items = R.n_items; P.wave_batch = wave_batch;
     P.tail_guard = (uint32_t)std::min<uint64_t>((uint64_t)c->tune.tail_guard * lanes, 1ull << 30);
     P.walk_park = (uint32_t)c->tune.walk_park;

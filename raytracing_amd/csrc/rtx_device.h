@@ -64,10 +64,12 @@ struct TraceParams {
     const float4*   grid_recs;   // 2 per entry: (cx, cy, cz, r) of the registered sphere -- a copy, so that a test is one fetch --, (its index, -, -, -)
     const uint32_t* grid_big;  // grid.n_big spheres tested for every ray
     const float4* exact;    // n x (cx, cy, cz, r)                   -- sphere.h:24-28 geometry, as uploaded
-    const uint4*  mat;      // 2n: [2i] = (type, albedo r, g, b), [2i+1] = (blur, ior, 0, 0), float bits
+    const uint4*  mat;      // 2n: [2i] = (type, albedo r, g, b), [2i+1] = (blur, ior, 1.0 / (double)radius: low word, high word), float bits;
+                            // glass (material.cu:69-105 reads neither albedo nor blur): albedo r holds ((1 - ior) / (1 + ior))^2, blur 1.0f / ior
     uint32_t      n, n_pad;
     rtx_camera    cam;
     uint32_t      cols, rows, npix;
+    double        inv_cols, inv_rows;   // 1.0 / (double)cols, 1.0 / (double)rows (phase (B)'s two divisions)
     uint32_t      spp_begin, spp_count, chunk_spp, nchunks;   // chunk_spp != 0: uniform chunks; 0: chunk k covers samples [chunk_tab[k], chunk_tab[k+1]) of the range
     uint32_t      chunk_tab[kMaxPlanChunks + 1];
     uint32_t      max_depth, key0, key1, flags;

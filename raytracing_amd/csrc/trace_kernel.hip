@@ -331,8 +331,10 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             const uint32_t px = pix - prow * P.cols, py = prow;
             float      b[4];
             rng_block(P, pix, s_cur, 0, 0, b);
-            float u = (float)((float)px + b[0]) / (float)P.cols;
-            float v = (float)((float)py + b[1]) / (float)P.rows;
+            // (x + jitter) / cols as (float)((double)numerator * (1.0 / (double)cols)): the identity of `quot` below (a float quotient through a
+            // double reciprocal, checked on the device); numerator and result are zero or normal here, the reciprocals come from the host
+            float u = (float)((double)((float)px + b[0]) * P.inv_cols);
+            float v = (float)((double)((float)py + b[1]) * P.inv_rows);
             // randomOnUnitDisk, utils.cu:85-94: try 0 from words (2,3) of block 0, try t>=1 from block (t+1)/2
             float    dkx = 2.0f * b[2] - 1.0f, dky = 2.0f * b[3] - 1.0f;
             bool     pending = go && (((dkx * dkx) + (dky * dky)) + 0.0f >= 1.0f);
@@ -904,7 +906,14 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             blur   = __uint_as_float(m1.x);
             ior    = __uint_as_float(m1.y);
             hp     = add(o, scale(closest, d));                          // ray.h:16
-            hn     = divs(sub(hp, mk(s.x, s.y, s.z)), s.w);              // sphere.cpp:84
+            // sphere.cpp:84, normal = (point - centre) / radius: three divisions by the sphere's radius, taken through its double reciprocal
+            // from the table (m1.z, m1.w; the identity of `quot`).  That identity leaves out results that round into the subnormal range:
+            // a lane with a component below 2^-120 (an exact zero included) divides.
+            const V3     pc  = sub(hp, mk(s.x, s.y, s.z));
+            const double rdr = __hiloint2double((int)m1.w, (int)m1.z);
+            hn = mk((float)((double)pc.x * rdr), (float)((double)pc.y * rdr), (float)((double)pc.z * rdr));
+            if (!(__builtin_fabsf(hn.x) >= 7.5231638e-37f && __builtin_fabsf(hn.y) >= 7.5231638e-37f && __builtin_fabsf(hn.z) >= 7.5231638e-37f))
+                hn = divs(pc, s.w);
         }
 
         RTX_STAMP(4);
@@ -986,7 +995,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     cosine  = ior * dot(d, hn) / dlen;
                 } else {
                     outward = hn;
-                    ni      = 1.0f / ior;
+                    ni      = blur;                                        // 1.0f / ior, divided on the host: a glass sphere's blur word (material.cu:69-105 reads no blur)
                     cosine  = -dot(d, hn) / dlen;
                 }
                 // _refract, material.cu:118-129
@@ -998,8 +1007,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 if (disc > 0) {
                     refracted = sub(scale(ni, sub(uv, scale(dt, outward))), scale(sqrt_rn(disc), outward));
                     // _schlick, material.cu:132-138: pow(float,int) promotes to double
-                    float  r0 = (1.0f - ior) / (1.0f + ior);
-                    r0        = r0 * r0;
+                    const float r0 = albedo.x;                             // ((1 - ior) / (1 + ior))^2 from the host: a glass sphere's first albedo word (its attenuation is (1, 1, 1))
                     double x  = (double)(1.0f - cosine);
                     double x2 = x * x;
                     double x5 = (x2 * x2) * x;
