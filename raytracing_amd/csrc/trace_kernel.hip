@@ -186,6 +186,15 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     uint32_t* const           queue  = reinterpret_cast<uint32_t*>(wave_lds + 160);   // 256 entries
     uint2* const              wordq  = reinterpret_cast<uint2*>(wave_lds + 224);      // 128 entries (MFMA filter)
 
+    // The kernel's parameters live in the kernel-argument segment.  Held in scalar registers for the whole kernel they do not fit: the
+    // compiler spills them to vector lanes and every use becomes a v_readlane -- a vector instruction in a loop that is bound by the vector
+    // instructions it issues.  So the phases that run once per iteration read what they need from the segment when they run (scalar loads,
+    // served by the scalar cache); the empty asm keeps the compiler from hoisting the loads out of the loop again.
+    auto kargs = [&]() {
+        const char __attribute__((address_space(4)))* k_ = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(k_));
+        return (const TraceParams __attribute__((address_space(4)))*)k_;
+    };
     // wave-level work reservation: [w_next, w_end) is owned, pf holds the next reservation (lane 0's value)
     uint32_t pf = 0;
     if (lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
@@ -202,12 +211,12 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
     // a reservation is one batch.  Which strip and chunk a batch is, is wave-uniform (scalar registers, one scalar load per
     // batch); a lane's item is the batch's pixel base + its offset.
     uint32_t cur_base = 0u, cur_chunk = 0u;
-    auto batch_info = [&](uint32_t start, uint32_t& base, uint32_t& chunk) {
-        const uint32_t e = start < P.n_items ? P.order[start >> 6] : 0xFFFFFFFFu;
+    auto batch_info = [&](const TraceParams __attribute__((address_space(4)))* Q, uint32_t start, uint32_t& base, uint32_t& chunk) {
+        const uint32_t e = start < Q->n_items ? Q->order[start >> 6] : 0xFFFFFFFFu;
         chunk = e >> 22;
         base  = e == 0xFFFFFFFFu ? 0xFFFFFFC0u : ((e & 0x3FFFFFu) << 6);    // past the end: no pixel of the batch is valid
     };
-    if (P.order) batch_info(w_next, cur_base, cur_chunk);
+    if (P.order) batch_info(kargs(), w_next, cur_base, cur_chunk);
 
     // per-lane path state
     uint32_t st = kNeedItem, item = 0, pix = 0, prow = 0, s_cur = 0, s_end = 0, bounce = 0;
@@ -255,26 +264,27 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         // ---- (A) lanes whose item is finished take the next one (persistent tile fetch) -------------------------
         uint64_t need = __ballot(st == kNeedItem);
         if (need) {
+            const TraceParams __attribute__((address_space(4)))* const PA = kargs();
             uint32_t cnt = (uint32_t)__popcll(need), r = rank_in(need), avail = w_end - w_next;
             uint32_t chunk = 0u, npx = 0xFFFFFFFFu;      // the lane's new item: (chunk, pixel); pixel >= npix: none
             bool     dry = false;
-            if (P.order) {
+            if (PA->order) {
                 // strip batches of 64: the lane's pixel is its batch's base + its offset in the batch
                 uint32_t base = cur_base, off = (w_next + 64u - w_end) + r;
                 chunk = cur_chunk;
                 if (cnt <= avail) {
                     w_next += cnt;
                 } else {
-                    if (!have_pf && lane == 0) pf = atomicAdd(P.work_counter, 64u);
+                    if (!have_pf && lane == 0) pf = atomicAdd(PA->work_counter, 64u);
                     const uint32_t nb = uniform(pf);
                     uint32_t nbase, nchunk;
-                    batch_info(nb, nbase, nchunk);
+                    batch_info(PA, nb, nbase, nchunk);
                     if (r >= avail) { base = nbase; chunk = nchunk; off = r - avail; }
                     w_next = nb + (cnt - avail);
                     w_end  = nb + 64u;
                     cur_base = nbase; cur_chunk = nchunk;
-                    have_pf = w_end + P.tail_guard < P.n_items;
-                    if (have_pf && lane == 0) pf = atomicAdd(P.work_counter, 64u);
+                    have_pf = w_end + PA->tail_guard < PA->n_items;
+                    if (have_pf && lane == 0) pf = atomicAdd(PA->work_counter, 64u);
                 }
                 npx = base + off;
                 dry = base == 0xFFFFFFC0u;
@@ -284,17 +294,17 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                     it = w_next + r;
                     w_next += cnt;
                 } else {
-                    if (!have_pf && lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
+                    if (!have_pf && lane == 0) pf = atomicAdd(PA->work_counter, PA->wave_batch);
                     uint32_t nb = uniform(pf);
                     it     = (r < avail) ? (w_next + r) : (nb + (r - avail));
                     w_next = nb + (cnt - avail);
-                    w_end  = nb + P.wave_batch;
-                    have_pf = w_end + P.tail_guard < P.n_items;
-                    if (have_pf && lane == 0) pf = atomicAdd(P.work_counter, P.wave_batch);
+                    w_end  = nb + PA->wave_batch;
+                    have_pf = w_end + PA->tail_guard < PA->n_items;
+                    if (have_pf && lane == 0) pf = atomicAdd(PA->work_counter, PA->wave_batch);
                 }
-                if (it < P.n_items) {
-                    chunk = it / P.npix;
-                    npx   = it - chunk * P.npix;
+                if (it < PA->n_items) {
+                    chunk = it / PA->npix;
+                    npx   = it - chunk * PA->npix;
                 } else {
                     dry = true;
                 }
@@ -302,18 +312,18 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             if (st == kNeedItem) {
                 if (dry) {
                     st = kDead;
-                } else if (npx < P.npix) {                 // (the last strip of an ordered list may reach past the image: such a lane asks again)
+                } else if (npx < PA->npix) {                 // (the last strip of an ordered list may reach past the image: such a lane asks again)
                     pix            = npx;
-                    item           = chunk * P.npix + pix;
+                    item           = chunk * PA->npix + pix;
                     item_rays      = 0u;
-                    prow           = pix / P.cols;                     // once per item, not per sample
-                    if (P.chunk_spp) {                                    // uniform chunks (caller's choice)
-                        s_cur          = P.spp_begin + chunk * P.chunk_spp;
-                        uint32_t e     = s_cur + P.chunk_spp, lim = P.spp_begin + P.spp_count;
+                    prow           = pix / PA->cols;                     // once per item, not per sample
+                    if (PA->chunk_spp) {                                    // uniform chunks (caller's choice)
+                        s_cur          = PA->spp_begin + chunk * PA->chunk_spp;
+                        uint32_t e     = s_cur + PA->chunk_spp, lim = PA->spp_begin + PA->spp_count;
                         s_end          = e < lim ? e : lim;
                     } else {                                              // the launch's chunk plan
-                        s_cur = P.spp_begin + ctab[chunk];
-                        s_end = P.spp_begin + ctab[chunk + 1u];
+                        s_cur = PA->spp_begin + ctab[chunk];
+                        s_end = PA->spp_begin + ctab[chunk + 1u];
                     }
                     acc            = mk(0, 0, 0);
                     st             = kNeedSample;
@@ -441,24 +451,29 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
             }
             RTX_STAMP(8);      // (grid: the big list)
             bool scan_all = false;
-            if (P.grid.dim[0] != 0u) {
+            // the grid's 24 constants are read from the kernel-argument segment here, in every iteration, like the camera's in phase (B): kept in
+            // scalar registers for the whole kernel they are spilled to vector lanes and come back as v_readlane in every set-up
+            const char __attribute__((address_space(4)))* gargs = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(gargs));
+            const GridDesc __attribute__((address_space(4)))* const G = (const GridDesc __attribute__((address_space(4)))*)(gargs + offsetof(TraceParams, grid));
+            if (G->dim[0] != 0u) {
                 const float inf = __builtin_inff();
-                const float slack_t = 2.0f * P.grid.pad * __builtin_amdgcn_rsqf(a);        // twice the walk's slack, as a ray parameter
+                const float slack_t = 2.0f * G->pad * __builtin_amdgcn_rsqf(a);        // twice the walk's slack, as a ray parameter
                 // Is the origin within the registrations' reach?  If some binned sphere can be farther away than the outermost tier
                 // allows, the ray is clipped against the box grown by the blur of that distance and, if it enters, scans the table.
                 const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
                 float s_near2 = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float lo = P.grid.gmin[k], hi = lo + (float)P.grid.dim[k] * P.grid.h[k];
+                    const float lo = G->gmin[k], hi = lo + (float)G->dim[k] * G->h[k];
                     const float off = fmaxf(fmaxf(lo - oo[k], oo[k] - hi), 0.0f);
                     s_near2 += off * off;
                 }
                 // (the walk only needs conservative values here: hardware sqrt / rcp, 1 ulp, with margins of 1e-5 -- its results do not depend on them)
-                const float l_far = __builtin_amdgcn_sqrtf(s_near2) * 1.00001f + P.grid.box_diag;
-                const bool  far   = !(l_far <= P.grid.far_l);                               // also NaN
-                const float rm    = P.grid.r_min;
-                const float extra = far ? P.grid.pad + (__builtin_amdgcn_sqrtf(rm * rm + 1.9073486328125e-6f * (l_far * l_far + rm * rm)) * 1.00001f - rm) : 0.0f;
+                const float l_far = __builtin_amdgcn_sqrtf(s_near2) * 1.00001f + G->box_diag;
+                const bool  far   = !(l_far <= G->far_l);                               // also NaN
+                const float rm    = G->r_min;
+                const float extra = far ? G->pad + (__builtin_amdgcn_sqrtf(rm * rm + 1.9073486328125e-6f * (l_far * l_far + rm * rm)) * 1.00001f - rm) : 0.0f;
                 // slab clip of the ray against the grid box; a zero component of d leaves that axis unbounded when the origin is inside
                 float    t_in = 0.0f, t_out = inf;
                 bool     walking = tracing;
@@ -466,7 +481,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 bool     moving[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float lo = P.grid.gmin[k] - extra, hi = P.grid.gmin[k] + (float)P.grid.dim[k] * P.grid.h[k] + extra;
+                    const float lo = G->gmin[k] - extra, hi = G->gmin[k] + (float)G->dim[k] * G->h[k] + extra;
                     inv[k] = __builtin_amdgcn_rcpf(dd[k]);          // off by an ulp: cell-exit parameters move by 1e-7 of themselves, the slack is 2^-12 of the extent
                     moving[k] = __builtin_fabsf(inv[k]) < inf;      // a zero (or denormal: v_rcp gives inf) component does not move the ray along this axis
                     if (moving[k]) {
@@ -486,18 +501,18 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 float    tn[3], dt[3];
                 int      cstride[3];
                 uint32_t rem = 0u, cidx = 0u;
-                const uint32_t stride[3] = { 1u, P.grid.dim[0], P.grid.dim[0] * P.grid.dim[1] };
+                const uint32_t stride[3] = { 1u, G->dim[0], G->dim[0] * G->dim[1] };
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float p = oo[k] + t_in * dd[k];
-                    int c = (int)floorf((p - P.grid.gmin[k]) * P.grid.inv_h[k]);
-                    c = c < 0 ? 0 : (c >= (int)P.grid.dim[k] ? (int)P.grid.dim[k] - 1 : c);
+                    int c = (int)floorf((p - G->gmin[k]) * G->inv_h[k]);
+                    c = c < 0 ? 0 : (c >= (int)G->dim[k] ? (int)G->dim[k] - 1 : c);
                     cidx += (uint32_t)c * stride[k];
                     const bool fwd = dd[k] > 0.0f;
                     if (moving[k]) {
-                        tn[k] = (P.grid.gmin[k] + (float)(c + (fwd ? 1 : 0)) * P.grid.h[k] - oo[k]) * inv[k];
-                        dt[k] = P.grid.h[k] * __builtin_fabsf(inv[k]);
-                        rem  |= (uint32_t)(fwd ? (int)P.grid.dim[k] - 1 - c : c) << (10 * k);
+                        tn[k] = (G->gmin[k] + (float)(c + (fwd ? 1 : 0)) * G->h[k] - oo[k]) * inv[k];
+                        dt[k] = G->h[k] * __builtin_fabsf(inv[k]);
+                        rem  |= (uint32_t)(fwd ? (int)G->dim[k] - 1 - c : c) << (10 * k);
                     } else {
                         tn[k] = inf;
                         dt[k] = 0.0f;
@@ -508,7 +523,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
                 // box's exit or the hit already found on the big list (the ground), whichever is nearer -- one decision per ray
                 // instead of one per cell (the outermost tier is valid wherever the origin passed the test above).
                 const float s_max = fminf(t_out, closest + slack_t) * (__builtin_amdgcn_sqrtf(a) * 1.00001f);     // as a distance, rounded up
-                const bool  tier1_fresh = !(s_max <= P.grid.tier_s[0]), tier2_fresh = !(s_max <= P.grid.tier_s[1]);   // NaN: the widest lists
+                const bool  tier1_fresh = !(s_max <= G->tier_s[0]), tier2_fresh = !(s_max <= G->tier_s[1]);   // NaN: the widest lists
                 uint32_t it = 0u, it_end = 0u;
                 bool     fresh_cell = true;
                 // Lane decoupling: a wave's walk lasts as long as its longest ray's, and most of its trips run for a
@@ -891,8 +906,9 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
 
         // ---- (D) shade: raytracer.cpp:250-270 + material.cu ------------------------------------------------------
         bool ended = false, absorbed = false, depth_end = false;
+        const TraceParams __attribute__((address_space(4)))* const PD = kargs();
         if (fin) {
-            if (P.primary && bounce == 0) P.primary[(size_t)(s_cur - P.spp_begin) * P.npix + pix] = best;
+            if (PD->primary && bounce == 0) PD->primary[(size_t)(s_cur - PD->spp_begin) * PD->npix + pix] = best;
         }
         const bool hit = fin && (best != kNoHit);
         uint32_t   mtype = 0;
@@ -900,7 +916,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
         float      blur = 0, ior = 1;
         if (hit) {
             const float4 s  = exact[best];
-            const uint4  m0 = P.mat[2u * best], m1 = P.mat[2u * best + 1u];
+            const uint4  m0 = PD->mat[2u * best], m1 = PD->mat[2u * best + 1u];
             mtype  = m0.x;
             albedo = mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w));
             blur   = __uint_as_float(m1.x);
@@ -1072,7 +1088,7 @@ __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(
 #ifdef RTX_WAVE_TIMES
                 wt_last_t0 = wt_item_t0; wt_last_rays = item_rays; wt_last_pix = pix; wt_last_len = s_end;
 #endif
-                P.partials[item] = make_float4(acc.x, acc.y, acc.z, __uint_as_float(item_rays));
+                kargs()->partials[item] = make_float4(acc.x, acc.y, acc.z, __uint_as_float(item_rays));
                 st = kNeedItem;
             } else {
                 st = kNeedSample;
