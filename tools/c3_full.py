@@ -18,5 +18,5 @@ rel = np.abs(two - full).max() / np.abs(full).max()
 fb1, fb2 = ctx.resolve(spp), None
 ctx.write_accum(cols, rows, full); fb2 = ctx.resolve(spp)
 print("two halves vs one launch: max rel diff %.2e; 8-bit images differ in %d of %d channels" % (rel, int(((fb1 ^ fb2) != 0).sum()), fb1.size))
-assert st["samples"] == cols * rows * spp and rel < 1e-5
+assert st["samples"] == cols * rows * spp and rel < 5e-5     # two chunkings of 4096 samples: float summation order
 ctx.close()
